@@ -1,0 +1,106 @@
+"""CPU suite: the oracle (oracle/sr_oracle.c) against the golden vectors the REAL reference produced
+(tests/golden/, generator oracle/gen_golden.py), and -- where oracle/_ref was built -- against the
+reference itself on fresh random cases."""
+import os
+
+import numpy as np
+import pytest
+
+from speechrecognition_amd import synth
+from tests.util import GOLDEN, Case, golden_names
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_oracle_matches_golden(name, oracle_lib, tmp_path):
+    c = Case(name, tmp_path)
+    if "model_digest" in c.z:
+        from oracle.gen_golden import spec_digest
+        assert spec_digest(c.spec) == str(c.z["model_digest"]), "synthetic generator drifted from the fixture"
+    o = c.oracle(oracle_lib)
+    scores = o.score_matrix(c.feats)
+    c.check_scores(scores, exact=True)
+    if c.max_approx and "argmin" in c.z and c.z["argmin"].size:
+        assert np.array_equal(o.argmin_matrix(c.feats), c.z["argmin"].astype(np.uint32))
+    assert np.array_equal(o.decode(c.feats), c.z["words"])
+    # decoder fed from the dense table gives the same result as lazy scoring
+    assert np.array_equal(o.decode(c.feats, dense=scores), c.z["words"])
+    if "align_ref" in c.z:
+        st, cost = o.align_full(c.feats, c.z["align_ref"])
+        assert np.array_equal(st, c.z["align_full_states"]) and cost == float(c.z["align_full_cost"])
+        st, cost = o.align_full(c.feats, c.z["align_ref"], dense=scores)
+        assert np.array_equal(st, c.z["align_full_states"]) and cost == float(c.z["align_full_cost"])
+        i = 0
+        while f"align_pruned_thr{i}" in c.z:
+            st, cost = o.align_pruned(c.feats, c.z["align_ref"], float(c.z[f"align_pruned_thr{i}"]))
+            assert np.array_equal(st, c.z[f"align_pruned_states{i}"])
+            assert cost == float(c.z[f"align_pruned_cost{i}"])
+            i += 1
+    o.close()
+
+
+def test_edit_distance_golden(oracle_lib, tmp_path):
+    z = np.load(os.path.join(GOLDEN, "edit_distance.npz"))
+    c = Case("cfg1_monophone", tmp_path)
+    o = c.oracle(oracle_lib)
+    for i in range(len(z["out"])):
+        r = z["ref_flat"][z["ref_off"][i]:z["ref_off"][i + 1]]
+        h = z["hyp_flat"][z["hyp_off"][i]:z["hyp_off"][i + 1]]
+        assert np.array_equal(o.edit_distance(r, h), z["out"][i]), (r, h)
+    o.close()
+
+
+def test_oracle_rejects_bad_files(oracle_lib, tmp_path):
+    p = tmp_path / "bad.mix"
+    p.write_bytes(b"NOTAMIX\0" + b"\0" * 64)
+    with pytest.raises(RuntimeError, match="Invalid magic header"):
+        oracle_lib.Oracle(str(p), 39, synth.make_lexicon(1))
+    c = Case("cfg1_monophone", tmp_path)
+    with pytest.raises(RuntimeError, match="Invalid dimension"):
+        oracle_lib.Oracle(c.mixset_path, 38, c.lex)
+
+
+def test_recognize_batch_matches_single(oracle_lib, tmp_path):
+    c = Case("toy7_d39", tmp_path)
+    o = c.oracle(oracle_lib)
+    feats, off = synth.make_batch(5, 20, 40, c.dim, seed=3)
+    for nt in (1, 2):
+        words, woff, secs = o.recognize_batch(feats, off, n_threads=nt)
+        assert secs >= 0
+        for u in range(5):
+            w = o.decode(feats[int(off[u]):int(off[u + 1])])
+            assert np.array_equal(w, words[int(woff[u]):int(woff[u + 1])])
+    o.close()
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/src/sietill/Mixtures.cpp"), reason="reference sources not present")
+@pytest.mark.parametrize("seed", [101, 102, 103])
+def test_oracle_vs_compiled_reference_random(seed, oracle_lib, tmp_path):
+    """Fresh random set-ups against the compiled reference itself (build container only)."""
+    po = oracle_lib
+    if not po.reference_available():
+        pytest.skip("oracle/_ref not built")
+    rng = np.random.default_rng(seed)
+    W, spw, reps = int(rng.integers(2, 25)), int(rng.integers(2, 5)), int(rng.integers(1, 3))
+    D = int(rng.choice([25, 38, 39]))
+    lex = synth.make_lexicon(W, spw, reps)
+    spec = synth.make_mixset(lex.n_states, rng.integers(1, 5, size=lex.n_states), D, seed=seed)
+    mp, cp = str(tmp_path / "m.mix"), str(tmp_path / "c.json")
+    beam = float(rng.choice([15.0, 40.0, 200.0]))
+    synth.write_mixset(mp, spec)
+    synth.write_config(cp, mp, am_threshold=beam)
+    feats = synth.make_features(int(rng.integers(40, 120)), D, seed + 1)
+    ref = po.Reference(cp, D, lex)
+    orc = po.Oracle(mp, D, lex, am_threshold=beam)
+    assert np.array_equal(ref.score_matrix(feats).view(np.uint64), orc.score_matrix(feats).view(np.uint64))
+    assert np.array_equal(ref.decode(feats), orc.decode(feats))
+    word_off, aut, sil = lex.flatten()
+    seq = [sil]
+    for w in rng.integers(1, lex.n_words, size=2):
+        seq += list(aut[word_off[w]:word_off[w + 1]]) + [sil]
+    seq = np.asarray(seq, np.uint16)
+    a, b = ref.align_full(feats, seq), orc.align_full(feats, seq)
+    assert np.array_equal(a[0], b[0]) and a[1] == b[1]
+    a, b = ref.align_pruned(feats, seq, 30.0), orc.align_pruned(feats, seq, 30.0)
+    assert np.array_equal(a[0], b[0]) and a[1] == b[1]
+    ref.close()
+    orc.close()
