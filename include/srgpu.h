@@ -1,0 +1,153 @@
+/*
+ * srgpu.h -- C ABI of libsrgpu.so: MI355X (gfx950) GMM acoustic scorer + Viterbi decoder/aligner.
+ *
+ * Drop-in boundary for the hot path of kkromberg/SpeechRecognition's `sietill` recogniser.
+ * Every entry point names the reference interface it replaces (paths relative to the reference
+ * repository root, src/sietill/...).  Plain pointers and sizes only; no C++/torch types; all
+ * functions return 0 on success or a negative SR_E* code, with a thread-local message in
+ * sr_last_error().  No exceptions cross this boundary.
+ *
+ * Conventions (same as the reference):
+ *   scores   negative natural-log likelihoods (costs, lower is better), IEEE double
+ *   features float32, row-major [frames x dim], utterances concatenated (Corpus layout,
+ *            Corpus.cpp:89-111); offsets here are in FRAMES, not floats
+ *   states   mixture (= HMM state) indices; words are indices into the lexicon
+ *
+ * Ownership: the caller owns every host buffer; handles own their device memory.  Model and
+ * lexicon are immutable after creation.  A handle is bound to one HIP device and must be used by
+ * one host thread at a time (one handle per GPU; utterance batches shard across GPUs with no
+ * collective, Recognizer.cpp:46-47).
+ */
+#ifndef SRGPU_H
+#define SRGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define SR_API __attribute__((visibility("default")))
+#else
+#define SR_API
+#endif
+
+#define SR_OK 0
+#define SR_EINVAL (-1)   /* bad argument (message says which) */
+#define SR_EHIP (-2)     /* HIP runtime error */
+#define SR_ENODEV (-3)   /* no usable gfx950 device */
+#define SR_ELIMIT (-4)   /* size outside what the kernels support (message says which) */
+
+/* GMM scoring kernels (MixtureModel::score, Mixtures.cpp:737-744) */
+#define SR_GMM_MFMA 0   /* FP64 MFMA contraction + fused min / log-sum epilogue (default; ~1e-15 rel.) */
+#define SR_GMM_EXACT 1  /* direct form replaying density_score_sse's operation order (Mixtures.cpp:645-690): bit-exact */
+
+typedef struct sr_model sr_model;     /* replaces MixtureModel as a FeatureScorer (Mixtures.hpp:18, FeatureScorer.hpp:12-16) */
+typedef struct sr_corpus sr_corpus;   /* replaces Corpus' feature store (Corpus.hpp:79-84, Corpus.cpp:141-144) */
+typedef struct sr_lexicon sr_lexicon; /* replaces Lexicon + TdpModel as search network (Lexicon.hpp:16-33, TdpModel.hpp:13-29) */
+
+SR_API const char* sr_last_error(void);
+SR_API int sr_device_count(int* count);
+
+/* ---- model ------------------------------------------------------------------------------------
+ * Finalised tables as MixtureModel holds them after read()+finalize() (Mixtures.cpp:374-461,
+ * Mixtures.hpp:71-84), expanded per density (tied variances repeated):
+ *   dens_off[n_states+1]  densities of state s are rows dens_off[s] .. dens_off[s+1]-1
+ *   means, inv_vars       [C x dim] doubles (means_, vars_inv_);  norm, logw  [C] (norm_, mean_weights_log_)
+ *   max_approx            1: min_score (Mixtures.cpp:696-713), 0: sum_score (:719-728)
+ * Limits: dim <= 63, C < 2^31.  (The reference itself stops at 65535 densities, Mixtures.cpp:766.) */
+SR_API int sr_model_create(int device, uint32_t dim, uint32_t n_states, const uint32_t* dens_off,
+                    const double* means, const double* inv_vars, const double* norm, const double* logw,
+                    int max_approx, sr_model** out);
+/* MixtureModel(config, dim, ...) with "load-mixtures-from" (Mixtures.cpp:156-174): reads a MIXSET v2
+ * file (read(), :748-830), derives the tables (finalize(), :374-461) on the host and creates the
+ * device model.  pooling: 0 global, 1 mixture, 2 none (MixtureModel::VarianceModel, Mixtures.hpp:20-24).
+ * Malformed files return SR_EINVAL with the reference's message instead of abort() (Mixtures.cpp:97-102). */
+SR_API int sr_model_load_mixset(const char* path, uint32_t dim, int pooling, int max_approx, int device, sr_model** out);
+SR_API int sr_model_destroy(sr_model* m);
+SR_API int sr_model_info(const sr_model* m, uint32_t* dim, uint32_t* n_states, uint64_t* n_densities);
+
+/* ---- corpus / frame-batch feeder (Corpus.cpp:89-111) --------------------------------------------
+ * Copies n_utts concatenated utterances to the device. frame_off[n_utts+1], frame_off[0] == 0.
+ * The host buffer is borrowed for the duration of the call only. */
+SR_API int sr_corpus_upload(sr_model* m, const float* feats, const uint64_t* frame_off, uint32_t n_utts, sr_corpus** out);
+SR_API int sr_corpus_destroy(sr_corpus* c);
+
+/* ---- scoring: FeatureScorer::prepare_sequence + score (FeatureScorer.hpp:14-15) -------------------
+ * Dense table out[total_frames x n_states] (row-major, host memory): out[t*n_states+s] is what
+ * MixtureModel::score(frame t, s) returns.  This is the table a `GpuMixtureScorer::prepare_sequence`
+ * fills, exactly like NeuralNetwork::prepare_sequence does (NeuralNetwork.cpp:184-199). */
+SR_API int sr_score_corpus(sr_model* m, sr_corpus* c, int gmm_kernel, double* out);
+/* one-shot convenience over host features of a single sequence */
+SR_API int sr_score_frames(sr_model* m, const float* feats, uint64_t n_frames, int gmm_kernel, double* out);
+
+/* ---- search network ---------------------------------------------------------------------------
+ * Linear whole-word lexicon as Lexicon::add_word builds it (Lexicon.cpp:11-22): word w owns
+ * automaton[word_off[w] .. word_off[w+1]) (state ids with repetitions expanded,
+ * MarkovAutomaton.hpp:22-28).  tdp = {loop, forward, skip} (TdpModel.cpp:5-7); silence_state as
+ * TdpModel::silence_state.  The initial hypothesis sits at position 0 of word 0 like the
+ * reference's (Recognizer.cpp:120), which is a word end when word 0 (normally silence) has one
+ * position.  Limits: <= 65535 words, <= 8192 positions in total, some word with >= 2 positions. */
+SR_API int sr_lexicon_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, const uint16_t* automaton,
+                      uint32_t silence_idx, const double tdp[3], uint16_t silence_state, sr_lexicon** out);
+SR_API int sr_lexicon_destroy(sr_lexicon* l);
+
+typedef struct {
+  double am_threshold; /* "am-threshold", Recognizer.cpp:31 (beam) */
+  double word_penalty; /* "word-penalty", Recognizer.cpp:32 */
+  int gmm_kernel;      /* SR_GMM_MFMA or SR_GMM_EXACT */
+  int reserved;
+} sr_search_params;
+
+/* ---- decoder: Recognizer::recognize / recognizeSequence_pruned (Recognizer.cpp:38-92, :103-232) ---
+ * Scores every frame of the resident corpus and runs the beam Viterbi per utterance, all on the
+ * device.  out_words (capacity: total frames, a safe upper bound) receives the recognised word
+ * indices of all utterances back to back, silence removed; utterance u owns
+ * out_words[out_word_off[u] .. out_word_off[u+1]).
+ * Optional traceback dump (may be NULL), each [total_frames + n_utts]: entry frame_off[u]+u+t is
+ * traceback[t] of utterance u, t = 0..T_u (Recognizer.cpp:118,191-208). */
+SR_API int sr_recognize_corpus(sr_model* m, sr_corpus* c, sr_lexicon* l, const sr_search_params* p,
+                        uint32_t* out_words, uint64_t* out_word_off,
+                        double* tb_score, uint16_t* tb_word, uint16_t* tb_bkp);
+/* one-shot convenience: upload + recognise + free */
+SR_API int sr_recognize_batch(sr_model* m, sr_lexicon* l, const sr_search_params* p, const float* feats,
+                       const uint64_t* frame_off, uint32_t n_utts, uint32_t* out_words, uint64_t* out_word_off);
+
+/* ---- forced aligner: Aligner::align_sequence_full (Alignment.cpp:50-144) --------------------------
+ * Utterance u is aligned against automata[aut_off[u] .. aut_off[u+1]) (N_u state ids; training
+ * builds `sil w1 sil ... sil`, Training.cpp:239-253).  Requires 1 <= N_u <= T_u (the reference
+ * indexes T-sized cost arrays by position).  out_states[total_frames] receives
+ * AlignmentItem::state per frame (count = 1, weight = 1 implied, Alignment.cpp:131-134);
+ * out_cost[n_utts] the returned path cost. */
+SR_API int sr_align_corpus(sr_model* m, sr_corpus* c, const uint16_t* automata, const uint64_t* aut_off,
+                    const double tdp[3], uint16_t silence_state, int gmm_kernel,
+                    uint16_t* out_states, double* out_cost);
+
+/* Aligner::align_sequence_pruned (Alignment.cpp:149-288): beam `pruning_threshold` on the per-frame
+ * best, transition penalty keyed on the destination state, ends at the highest position reached. */
+SR_API int sr_align_corpus_pruned(sr_model* m, sr_corpus* c, const uint16_t* automata, const uint64_t* aut_off,
+                           const double tdp[3], uint16_t silence_state, double pruning_threshold, int gmm_kernel,
+                           uint16_t* out_states, double* out_cost);
+
+/* ---- measurement --------------------------------------------------------------------------------
+ * When enabled, every kernel launch of this model handle is bracketed by HIP events on the
+ * launch stream; sr_profile_read() synchronises and returns accumulated device times. */
+typedef struct {
+  double gmm_ms;        /* GMM scoring kernel(s) */
+  uint64_t gmm_launches;
+  double gmm_flops;     /* algorithmic: 4 * dim * densities * frames per launch, summed */
+  double search_ms;     /* Viterbi decode / align kernels */
+  uint64_t search_launches;
+  double search_bytes;  /* algorithmic: (8*S + 4*P) * frames (decode) / (8+1)*N * frames (align) */
+  uint64_t frames;      /* frames processed */
+} sr_profile;
+SR_API int sr_profile_enable(sr_model* m, int on);
+SR_API int sr_profile_reset(sr_model* m);
+SR_API int sr_profile_read(sr_model* m, sr_profile* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRGPU_H */

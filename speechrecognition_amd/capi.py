@@ -1,0 +1,228 @@
+"""ctypes binding of libsrgpu.so (include/srgpu.h) -- the product's C ABI.
+
+Used by tests/ and bench.py to drive the HIP path exactly as a foreign-language host would; no
+compute happens in Python and there is no fallback: if the library or a gfx950 device is missing
+the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsrgpu.so")
+
+GMM_MFMA, GMM_EXACT = 0, 1
+POOL_GLOBAL, POOL_MIXTURE, POOL_NONE = 0, 1, 2
+
+# every symbol include/srgpu.h declares
+SYMBOLS = [
+    "sr_last_error", "sr_device_count", "sr_model_create", "sr_model_load_mixset", "sr_model_destroy", "sr_model_info",
+    "sr_corpus_upload", "sr_corpus_destroy", "sr_score_corpus", "sr_score_frames", "sr_lexicon_create",
+    "sr_lexicon_destroy", "sr_recognize_corpus", "sr_recognize_batch", "sr_align_corpus", "sr_align_corpus_pruned",
+    "sr_profile_enable", "sr_profile_reset", "sr_profile_read",
+]
+
+
+class SrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libsrgpu error {code}: {msg}")
+        self.code = code
+
+
+class SearchParams(C.Structure):
+    _fields_ = [("am_threshold", C.c_double), ("word_penalty", C.c_double), ("gmm_kernel", C.c_int), ("reserved", C.c_int)]
+
+
+class Profile(C.Structure):
+    _fields_ = [("gmm_ms", C.c_double), ("gmm_launches", C.c_uint64), ("gmm_flops", C.c_double),
+                ("search_ms", C.c_double), ("search_launches", C.c_uint64), ("search_bytes", C.c_double),
+                ("frames", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib():
+    """Loads libsrgpu.so (built in-tree by speechrecognition_amd/build.py). Raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(LIB_PATH)
+        L.sr_last_error.restype = C.c_char_p
+        vp, u32, u64, i32, dbl = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_double
+        L.sr_device_count.argtypes = [C.POINTER(i32)]
+        L.sr_model_create.argtypes = [i32, u32, u32, vp, vp, vp, vp, vp, i32, C.POINTER(vp)]
+        L.sr_model_load_mixset.argtypes = [C.c_char_p, u32, i32, i32, i32, C.POINTER(vp)]
+        L.sr_model_destroy.argtypes = [vp]
+        L.sr_model_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u64)]
+        L.sr_corpus_upload.argtypes = [vp, vp, vp, u32, C.POINTER(vp)]
+        L.sr_corpus_destroy.argtypes = [vp]
+        L.sr_score_corpus.argtypes = [vp, vp, i32, vp]
+        L.sr_score_frames.argtypes = [vp, vp, u64, i32, vp]
+        L.sr_lexicon_create.argtypes = [vp, u32, vp, vp, u32, C.POINTER(dbl * 3), C.c_uint16, C.POINTER(vp)]
+        L.sr_lexicon_destroy.argtypes = [vp]
+        L.sr_recognize_corpus.argtypes = [vp, vp, vp, C.POINTER(SearchParams), vp, vp, vp, vp, vp]
+        L.sr_recognize_batch.argtypes = [vp, vp, C.POINTER(SearchParams), vp, vp, u32, vp, vp]
+        L.sr_align_corpus.argtypes = [vp, vp, vp, vp, C.POINTER(dbl * 3), C.c_uint16, i32, vp, vp]
+        L.sr_align_corpus_pruned.argtypes = [vp, vp, vp, vp, C.POINTER(dbl * 3), C.c_uint16, dbl, i32, vp, vp]
+        L.sr_profile_enable.argtypes = [vp, i32]
+        L.sr_profile_reset.argtypes = [vp]
+        L.sr_profile_read.argtypes = [vp, C.POINTER(Profile)]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise SrError(rc, lib().sr_last_error().decode(errors="replace"))
+
+
+def device_count():
+    n = C.c_int(0)
+    _check(lib().sr_device_count(C.byref(n)))
+    return n.value
+
+
+def _ptr(a):
+    return a.ctypes.data if a is not None else None
+
+
+class Model:
+    """sr_model handle: the GPU FeatureScorer (MixtureModel, sietill/Mixtures.hpp:18)."""
+
+    def __init__(self, handle):
+        self.h = handle
+        d, s, c = C.c_uint32(), C.c_uint32(), C.c_uint64()
+        _check(lib().sr_model_info(self.h, C.byref(d), C.byref(s), C.byref(c)))
+        self.dim, self.n_states, self.n_densities = d.value, s.value, c.value
+
+    @classmethod
+    def from_mixset(cls, path, dim, pooling=POOL_NONE, max_approx=True, device=0):
+        h = C.c_void_p()
+        _check(lib().sr_model_load_mixset(str(path).encode(), dim, pooling, int(max_approx), device, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_tables(cls, dens_off, means, inv_vars, norm, logw, max_approx=True, device=0):
+        dens_off = np.ascontiguousarray(dens_off, dtype=np.uint32)
+        means = np.ascontiguousarray(means, dtype=np.float64)
+        inv_vars = np.ascontiguousarray(inv_vars, dtype=np.float64)
+        norm = np.ascontiguousarray(norm, dtype=np.float64)
+        logw = np.ascontiguousarray(logw, dtype=np.float64)
+        h = C.c_void_p()
+        _check(lib().sr_model_create(device, means.shape[1], len(dens_off) - 1, _ptr(dens_off), _ptr(means), _ptr(inv_vars),
+                                     _ptr(norm), _ptr(logw), int(max_approx), C.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if self.h:
+            lib().sr_model_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- scoring -----------------------------------------------------------------------------------
+    def score_frames(self, feats, kernel=GMM_MFMA):
+        feats = np.ascontiguousarray(feats, dtype=np.float32)
+        out = np.empty((feats.shape[0], self.n_states), dtype=np.float64)
+        _check(lib().sr_score_frames(self.h, _ptr(feats), feats.shape[0], kernel, _ptr(out)))
+        return out
+
+    def upload(self, feats, frame_off):
+        return Corpus(self, feats, frame_off)
+
+    def lexicon(self, word_off, automaton, silence_idx, tdp, silence_state):
+        return Lexicon(self, word_off, automaton, silence_idx, tdp, silence_state)
+
+    # -- profiling ---------------------------------------------------------------------------------
+    def profile(self, on=True):
+        _check(lib().sr_profile_enable(self.h, int(on)))
+        _check(lib().sr_profile_reset(self.h))
+
+    def profile_read(self):
+        p = Profile()
+        _check(lib().sr_profile_read(self.h, C.byref(p)))
+        return {k: getattr(p, k) for k, _ in Profile._fields_}
+
+
+class Corpus:
+    """sr_corpus handle: device-resident utterance batch (Corpus layout, sietill/Corpus.cpp:89-111)."""
+
+    def __init__(self, model, feats, frame_off):
+        self.model = model
+        feats = np.ascontiguousarray(feats, dtype=np.float32)
+        self.frame_off = np.ascontiguousarray(frame_off, dtype=np.uint64)
+        self.n_utts = len(self.frame_off) - 1
+        self.n_frames = int(self.frame_off[-1])
+        self.h = C.c_void_p()
+        _check(lib().sr_corpus_upload(model.h, _ptr(feats), _ptr(self.frame_off), self.n_utts, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().sr_corpus_destroy(self.h)
+            self.h = None
+
+    def score(self, kernel=GMM_MFMA):
+        out = np.empty((self.n_frames, self.model.n_states), dtype=np.float64)
+        _check(lib().sr_score_corpus(self.model.h, self.h, kernel, _ptr(out)))
+        return out
+
+    def recognize(self, lexicon, am_threshold, word_penalty, kernel=GMM_MFMA, traceback=False):
+        """-> (words u32[], word_off u64[n_utts+1]) [, (tb_score, tb_word, tb_bkp)]"""
+        words = np.zeros(max(self.n_frames, 1), dtype=np.uint32)
+        woff = np.zeros(self.n_utts + 1, dtype=np.uint64)
+        sp = SearchParams(am_threshold, word_penalty, kernel, 0)
+        tbs = tbw = tbb = None
+        if traceback:
+            n = self.n_frames + self.n_utts
+            tbs, tbw, tbb = np.zeros(n, np.float64), np.zeros(n, np.uint16), np.zeros(n, np.uint16)
+        _check(lib().sr_recognize_corpus(self.model.h, self.h, lexicon.h, C.byref(sp), _ptr(words), _ptr(woff), _ptr(tbs),
+                                         _ptr(tbw), _ptr(tbb)))
+        words = words[: int(woff[-1])].copy()
+        if traceback:
+            return words, woff, (tbs, tbw, tbb)
+        return words, woff
+
+    def _aut(self, automata):
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.uint16) for a in automata]), dtype=np.uint16)
+        off = np.concatenate([[0], np.cumsum([len(a) for a in automata])]).astype(np.uint64)
+        return flat, off
+
+    def align(self, automata, tdp, silence_state, kernel=GMM_MFMA, pruning_threshold=None):
+        """automata: one state-id sequence per utterance -> (states u16[total_frames], cost f64[n_utts])"""
+        flat, off = self._aut(automata)
+        states = np.zeros(max(self.n_frames, 1), dtype=np.uint16)
+        cost = np.zeros(max(self.n_utts, 1), dtype=np.float64)
+        t3 = (C.c_double * 3)(*tdp)
+        if pruning_threshold is None:
+            _check(lib().sr_align_corpus(self.model.h, self.h, _ptr(flat), _ptr(off), C.byref(t3), silence_state, kernel,
+                                         _ptr(states), _ptr(cost)))
+        else:
+            _check(lib().sr_align_corpus_pruned(self.model.h, self.h, _ptr(flat), _ptr(off), C.byref(t3), silence_state,
+                                                float(pruning_threshold), kernel, _ptr(states), _ptr(cost)))
+        return states[: self.n_frames], cost[: self.n_utts]
+
+
+class Lexicon:
+    """sr_lexicon handle: flattened Lexicon + TdpModel (sietill/Lexicon.hpp:16-33, TdpModel.hpp:13-29)."""
+
+    def __init__(self, model, word_off, automaton, silence_idx, tdp, silence_state):
+        word_off = np.ascontiguousarray(word_off, dtype=np.uint32)
+        automaton = np.ascontiguousarray(automaton, dtype=np.uint16)
+        self.h = C.c_void_p()
+        t3 = (C.c_double * 3)(*tdp)
+        _check(lib().sr_lexicon_create(model.h, len(word_off) - 1, _ptr(word_off), _ptr(automaton), silence_idx, C.byref(t3),
+                                       silence_state, C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().sr_lexicon_destroy(self.h)
+            self.h = None

@@ -1,0 +1,26 @@
+// host_util.h -- small host-side helpers shared by the C-ABI translation units.
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#define SRHOST_POOL_GLOBAL 0   // MixtureModel::GLOBAL_POOLING  (sietill/Mixtures.hpp:20-24)
+#define SRHOST_POOL_MIXTURE 1  // MixtureModel::MIXTURE_POOLING
+#define SRHOST_POOL_NONE 2     // MixtureModel::NO_POOLING
+
+namespace srhost {
+
+// finalised tables, one row per density in mixture order (what sr_model_create consumes)
+struct MixsetTables {
+  uint32_t dim = 0;
+  std::vector<uint32_t> dens_off;
+  std::vector<double> means, inv_vars, norm, logw;
+};
+
+// returns nullptr on success or the reference's error text (sietill/Mixtures.cpp:753-825)
+const char* load_mixset(const char* path, uint32_t dim, int pooling, MixsetTables* out);
+
+// stores the message for sr_last_error() and returns `code`
+int set_error(int code, const char* msg);
+
+}  // namespace srhost

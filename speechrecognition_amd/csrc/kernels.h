@@ -1,0 +1,96 @@
+// kernels.h -- argument blocks and launchers of the gfx950 kernels behind libsrgpu.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace srgpu {
+
+// ---- GMM scoring, FP64 MFMA contraction (gmm_mfma.hip) ------------------------------------------
+struct GmmMfmaArgs {
+  const float* feats;           // [n_frames x dim] float32
+  uint64_t n_frames;
+  uint32_t dim;
+  const double* apack;          // [n_blocks][KSTEPS][64] model rows in MFMA A-fragment order
+  const uint32_t* blk_meta;     // [n_blocks] (group << 1) | last-block-of-group
+  const uint32_t* grp_state;    // [n_groups*4] state written by slot g of a group, 0xFFFFFFFF = padding
+  const uint32_t* split_begin;  // [ny+1] block range of each state-range split (group aligned)
+  double* out;                  // [n_frames x ld]
+  uint32_t ld;
+  uint32_t nx, ny;              // frame tiles x state-range splits
+};
+int gmm_mfma_ksteps_for_dim(uint32_t dim);   // 0 if dim unsupported
+int gmm_mfma_frames_per_tile(int ksteps);
+hipError_t launch_gmm_mfma(const GmmMfmaArgs& a, int ksteps, bool sum, hipStream_t stream);
+
+// ---- GMM scoring, direct form, bit-exact with the reference (gmm_exact.hip) ----------------------
+struct GmmExactArgs {
+  const float* feats;
+  uint64_t n_frames;
+  uint32_t dim;
+  uint32_t n_states;
+  const uint32_t* dens_off;  // [n_states+1]
+  const double* means;       // [C x dim]
+  const double* inv_vars;    // [C x dim]
+  const double* norm;        // [C]
+  const double* logw;        // [C]
+  double* out;               // [n_frames x ld]
+  uint32_t ld;
+  uint32_t states_per_split; // grid.y splits the state range
+};
+hipError_t launch_gmm_exact(const GmmExactArgs& a, bool sum, uint32_t n_splits, hipStream_t stream);
+
+// ---- beam Viterbi decoder (viterbi_decode.hip) ---------------------------------------------------
+// Search network flattened to "slots" = (word, position) pairs in (word, position) order, which is
+// the iteration order of the reference's hypothesis array (Recognizer.cpp:126).
+struct DecodeNet {
+  uint32_t n_slots;             // P
+  uint32_t n_words;
+  const uint32_t* slot_info;    // [P] packed per-slot constants, see viterbi_decode.hip
+  const uint32_t* slot_word;    // [P] word index of the slot
+  const uint32_t* word_end_slot;// [W] slot index of each word's last position
+  uint32_t silence_word;
+  double tdp_loop, tdp_forward, tdp_skip;
+  uint32_t silence_state;
+};
+struct DecodeArgs {
+  DecodeNet net;
+  const double* scores;         // [frames x ld] dense emission costs of this launch's frames
+  uint32_t ld;
+  const uint64_t* frame_off;    // [n_utts+1] global frame offsets of the corpus
+  uint64_t frame_base;          // scores row 0 is global frame `frame_base`
+  uint32_t utt_first, n_utts;   // utterances handled by this launch
+  double am_threshold, word_penalty;
+  // traceback arrays, entry frame_off[u] + u + t  (t = 0..T_u)
+  double* tb_score;
+  uint16_t* tb_word;
+  uint16_t* tb_bkp;
+  uint32_t* out_words;          // utterance u writes its words at out_words[frame_off[u] ...]
+  uint32_t* out_count;          // [n_utts_total]
+  uint32_t* out_flags;          // [n_utts_total] bit0: slow (sequential-emulation) path was taken
+};
+hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream);
+uint32_t decode_max_slots();
+
+// ---- forced aligners (viterbi_align.hip) ----------------------------------------------------------
+struct AlignArgs {
+  const double* scores;         // [frames x ld]
+  uint32_t ld;
+  const uint64_t* frame_off;    // [n_utts+1]
+  uint64_t frame_base;
+  uint32_t utt_first, n_utts;
+  const uint16_t* automata;     // concatenated reference automata
+  const uint64_t* aut_off;      // [n_utts_total+1]
+  double tdp_loop, tdp_forward, tdp_skip;
+  uint32_t silence_state;
+  double pruning_threshold;     // pruned variant only
+  uint8_t* backptr;             // workspace: [sum_u T_u * N_u] taken transition (0/1/2, 3 = none)
+  const uint64_t* bp_off;       // [n_utts_total+1] offsets into backptr
+  uint32_t max_positions;       // max N_u over the launch (sizes the LDS cost buffers)
+  uint16_t* out_states;         // [total frames]
+  double* out_cost;             // [n_utts_total]
+};
+hipError_t launch_align_full(const AlignArgs& a, hipStream_t stream);
+hipError_t launch_align_pruned(const AlignArgs& a, hipStream_t stream);
+uint32_t align_max_positions();
+
+}  // namespace srgpu

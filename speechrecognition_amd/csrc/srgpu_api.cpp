@@ -1,0 +1,723 @@
+// srgpu_api.cpp -- C ABI of libsrgpu.so (include/srgpu.h): handles, device memory, model packing,
+// the chunked score -> search pipeline on two HIP streams, and event-based kernel timing.
+//
+// Nothing here computes scores or paths on the host: every sr_score_* / sr_recognize_* / sr_align_*
+// call runs the HIP kernels of gmm_mfma.hip / gmm_exact.hip / viterbi_decode.hip / viterbi_align.hip
+// and fails loudly (SR_EHIP / SR_ENODEV) when no gfx950 device is usable.  There is no CPU fallback.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/srgpu.h"
+#include "host_util.h"
+#include "kernels.h"
+
+using namespace srgpu;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+}  // namespace
+namespace srhost {
+int set_error(int code, const char* msg) { return fail(code, "%s", msg); }
+}  // namespace srhost
+namespace {
+
+#define HIP_TRY(expr)                                                                             \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) return fail(SR_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t ensure(size_t count) {
+    if (count <= n && p) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; n = 0; }
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+  hipError_t upload(const T* src, size_t count) {
+    hipError_t e = ensure(count);
+    if (e != hipSuccess || count == 0) return e;
+    return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+};
+
+struct EventPair { hipEvent_t a, b; int kind; };  // kind 0 = gmm, 1 = search
+
+}  // namespace
+
+struct sr_model {
+  int device = 0;
+  uint32_t dim = 0, n_states = 0, ld = 0;
+  uint64_t n_dens = 0;
+  bool max_approx = true;
+  // exact-kernel tables (finalised, per density)
+  DevBuf<uint32_t> dens_off;
+  DevBuf<double> means, inv_vars, norm, logw;
+  // MFMA packing
+  int ksteps = 0;
+  uint32_t n_blocks = 0, n_groups = 0;
+  DevBuf<double> apack;
+  DevBuf<uint32_t> blk_meta, grp_state;
+  std::vector<uint32_t> group_first_block;  // host: [n_groups+1]
+  DevBuf<uint32_t> split_begin;
+  uint32_t split_ny = 0;
+  // streams / workspace
+  hipStream_t s_gmm = nullptr, s_search = nullptr;
+  DevBuf<double> scores[2];
+  hipEvent_t ev_scored[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
+  size_t chunk_frames = 0;
+  // profiling
+  bool profiling = false;
+  std::vector<EventPair> events;
+  sr_profile prof{};
+};
+
+struct sr_corpus {
+  sr_model* model = nullptr;
+  uint32_t n_utts = 0;
+  uint64_t n_frames = 0;
+  std::vector<uint64_t> frame_off;  // host copy
+  DevBuf<float> feats;
+  DevBuf<uint64_t> d_frame_off;
+  // search outputs (device)
+  DevBuf<double> tb_score;
+  DevBuf<uint16_t> tb_word, tb_bkp;
+  DevBuf<uint32_t> out_words, out_count, out_flags;
+  // aligner workspace
+  DevBuf<uint16_t> automata, out_states;
+  DevBuf<uint64_t> aut_off, bp_off;
+  DevBuf<uint8_t> backptr;
+  DevBuf<double> out_cost;
+};
+
+struct sr_lexicon {
+  sr_model* model = nullptr;
+  uint32_t n_words = 0, n_slots = 0, silence_idx = 0, silence_state = 0;
+  double tdp[3] = {0, 0, 0};
+  DevBuf<uint32_t> slot_info, slot_word, word_end_slot;
+};
+
+namespace {
+
+// ---- model packing for the MFMA kernel ---------------------------------------------------------
+// States are sorted by density count (stable, descending) and chunked into groups of four; group q
+// owns ceil(max_count/4) blocks of 16 model rows; row r of block j holds density 4*j + (r>>2) of the
+// group's state slot (r&3).  Fragment order: apack[block][kstep][lane] = A[row = lane&15][k = 4*kstep + (lane>>4)].
+int pack_model(sr_model* m, const uint32_t* dens_off, const double* means, const double* inv_vars,
+               const double* norm, const double* logw) {
+  const uint32_t S = m->n_states, D = m->dim;
+  const int KS = m->ksteps;
+  std::vector<uint32_t> order(S);
+  std::iota(order.begin(), order.end(), 0u);
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+    return (dens_off[x + 1] - dens_off[x]) > (dens_off[y + 1] - dens_off[y]);
+  });
+  const uint32_t n_groups = (S + 3) / 4;
+  std::vector<uint32_t> grp_state(4 * (size_t)n_groups, 0xFFFFFFFFu), first_block(n_groups + 1, 0);
+  for (uint32_t q = 0; q < n_groups; q++) {
+    uint32_t mx = 0;
+    for (uint32_t g = 0; g < 4; g++) {
+      const uint32_t i = 4 * q + g;
+      if (i < S) {
+        grp_state[4 * q + g] = order[i];
+        mx = std::max(mx, dens_off[order[i] + 1] - dens_off[order[i]]);
+      }
+    }
+    first_block[q + 1] = first_block[q] + std::max(1u, (mx + 3) / 4);
+  }
+  const uint32_t n_blocks = first_block[n_groups];
+  const size_t blk_doubles = (size_t)KS * 64;
+  std::vector<double> apack(blk_doubles * n_blocks, 0.0);
+  std::vector<uint32_t> meta(n_blocks);
+  const double inf = std::numeric_limits<double>::infinity();
+  for (uint32_t q = 0; q < n_groups; q++) {
+    for (uint32_t b = first_block[q]; b < first_block[q + 1]; b++) {
+      meta[b] = (q << 1) | (b + 1 == first_block[q + 1] ? 1u : 0u);
+      const uint32_t j = b - first_block[q];
+      for (uint32_t r = 0; r < 16; r++) {
+        const uint32_t g = r & 3, sub = r >> 2;
+        const uint32_t st = grp_state[4 * q + g];
+        const uint32_t i = 4 * j + sub;
+        const bool real = st != 0xFFFFFFFFu && i < dens_off[st + 1] - dens_off[st];
+        const size_t c = real ? (size_t)dens_off[st] + i : 0;
+        double konst = inf;  // padding row: +inf never wins the min and adds exp(-inf) = 0 to a sum
+        if (real) {
+          double q2 = 0.0;
+          for (uint32_t d = 0; d < D; d++) q2 += means[c * D + d] * means[c * D + d] * inv_vars[c * D + d];
+          konst = norm[c] - logw[c] + 0.5 * q2;
+        }
+        for (int ks = 0; ks < KS; ks++) {
+          for (uint32_t kk = 0; kk < 4; kk++) {
+            const uint32_t k = 4 * ks + kk;
+            double v = 0.0;
+            if (k < 2 * D) {
+              if (real) {
+                const uint32_t d = k >> 1;
+                v = (k & 1) ? -means[c * D + d] * inv_vars[c * D + d] : 0.5 * inv_vars[c * D + d];
+              }
+            } else if (k == 2 * D) {
+              v = konst;
+            }
+            apack[(size_t)b * blk_doubles + (size_t)ks * 64 + kk * 16 + r] = v;
+          }
+        }
+      }
+    }
+  }
+  m->n_groups = n_groups;
+  m->n_blocks = n_blocks;
+  m->group_first_block = first_block;
+  HIP_TRY(m->apack.upload(apack.data(), apack.size()));
+  HIP_TRY(m->blk_meta.upload(meta.data(), meta.size()));
+  HIP_TRY(m->grp_state.upload(grp_state.data(), grp_state.size()));
+  return SR_OK;
+}
+
+// choose the state-range split count for a launch over `nx` frame tiles and upload group-aligned ranges
+int set_splits(sr_model* m, uint32_t nx) {
+  // Equal-sized workgroups run in rounds of (2 per CU x 256 CUs); aim for ~32 rounds so the last,
+  // partly filled round costs ~3 %, but keep >= 32 model blocks (~70 us of MFMA work) per workgroup
+  // so the feature-tile prologue stays negligible.
+  const uint32_t target_wgs = 32 * 512;
+  uint32_t ny = (target_wgs + nx - 1) / std::max(1u, nx);
+  ny = std::max(1u, std::min(ny, std::min(m->n_groups, std::max(1u, m->n_blocks / 32))));
+  if (ny >= 8) ny &= ~7u;  // multiples of 8 enable the XCD-aware tile map
+  if (ny == m->split_ny) return SR_OK;
+  std::vector<uint32_t> sb(ny + 1);
+  for (uint32_t y = 0; y <= ny; y++) {
+    // balance by blocks, cut at group boundaries
+    const uint64_t want = (uint64_t)m->n_blocks * y / ny;
+    auto it = std::lower_bound(m->group_first_block.begin(), m->group_first_block.end(), (uint32_t)want);
+    sb[y] = *it;
+  }
+  sb[0] = 0;
+  sb[ny] = m->n_blocks;
+  HIP_TRY(hipStreamSynchronize(m->s_gmm));
+  HIP_TRY(m->split_begin.upload(sb.data(), sb.size()));
+  m->split_ny = ny;
+  return SR_OK;
+}
+
+int prof_begin(sr_model* m, hipStream_t s, int kind, EventPair* ep) {
+  if (!m->profiling) return SR_OK;
+  ep->kind = kind;
+  HIP_TRY(hipEventCreate(&ep->a));
+  HIP_TRY(hipEventCreate(&ep->b));
+  HIP_TRY(hipEventRecord(ep->a, s));
+  return SR_OK;
+}
+int prof_end(sr_model* m, hipStream_t s, EventPair* ep) {
+  if (!m->profiling) return SR_OK;
+  HIP_TRY(hipEventRecord(ep->b, s));
+  m->events.push_back(*ep);
+  return SR_OK;
+}
+
+// score frames [f_begin, f_end) of `feats` into `out` (device, row stride m->ld) on stream s_gmm
+int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm_kernel, double* d_out) {
+  if (n_frames == 0) return SR_OK;
+  EventPair ep{};
+  if (gmm_kernel == SR_GMM_MFMA) {
+    const uint32_t tile = gmm_mfma_frames_per_tile(m->ksteps);
+    const uint32_t nx = (uint32_t)((n_frames + tile - 1) / tile);
+    int rc = set_splits(m, nx);
+    if (rc) return rc;
+    GmmMfmaArgs a{};
+    a.feats = d_feats; a.n_frames = n_frames; a.dim = m->dim;
+    a.apack = m->apack.p; a.blk_meta = m->blk_meta.p; a.grp_state = m->grp_state.p; a.split_begin = m->split_begin.p;
+    a.out = d_out; a.ld = m->ld; a.nx = nx; a.ny = m->split_ny;
+    if ((rc = prof_begin(m, m->s_gmm, 0, &ep))) return rc;
+    HIP_TRY(launch_gmm_mfma(a, m->ksteps, !m->max_approx, m->s_gmm));
+    if ((rc = prof_end(m, m->s_gmm, &ep))) return rc;
+  } else if (gmm_kernel == SR_GMM_EXACT) {
+    GmmExactArgs a{};
+    a.feats = d_feats; a.n_frames = n_frames; a.dim = m->dim; a.n_states = m->n_states;
+    a.dens_off = m->dens_off.p; a.means = m->means.p; a.inv_vars = m->inv_vars.p; a.norm = m->norm.p; a.logw = m->logw.p;
+    a.out = d_out; a.ld = m->ld;
+    const uint32_t nx = (uint32_t)((n_frames + 255) / 256);
+    uint32_t ny = std::max(1u, std::min(m->n_states, (4096 + nx - 1) / nx));
+    a.states_per_split = (m->n_states + ny - 1) / ny;
+    ny = (m->n_states + a.states_per_split - 1) / a.states_per_split;
+    int rc;
+    if ((rc = prof_begin(m, m->s_gmm, 0, &ep))) return rc;
+    HIP_TRY(launch_gmm_exact(a, !m->max_approx, ny, m->s_gmm));
+    if ((rc = prof_end(m, m->s_gmm, &ep))) return rc;
+  } else {
+    return fail(SR_EINVAL, "unknown gmm_kernel %d", gmm_kernel);
+  }
+  if (m->profiling) m->prof.gmm_flops += 4.0 * m->dim * (double)m->n_dens * (double)n_frames;
+  return SR_OK;
+}
+
+// utterance chunks whose score table fits the workspace
+struct Chunk { uint32_t u0, u1; uint64_t f0, f1; };
+std::vector<Chunk> make_chunks(const sr_corpus* c, size_t chunk_frames) {
+  std::vector<Chunk> out;
+  uint32_t u = 0;
+  while (u < c->n_utts) {
+    uint32_t v = u + 1;
+    while (v < c->n_utts && c->frame_off[v + 1] - c->frame_off[u] <= chunk_frames) v++;
+    out.push_back({u, v, c->frame_off[u], c->frame_off[v]});
+    u = v;
+  }
+  return out;
+}
+
+int ensure_score_ws(sr_model* m, const std::vector<Chunk>& chunks) {
+  uint64_t mx = 0;
+  for (const Chunk& ch : chunks) mx = std::max(mx, ch.f1 - ch.f0);
+  const int nbuf = chunks.size() > 1 ? 2 : 1;
+  for (int i = 0; i < nbuf; i++) HIP_TRY(m->scores[i].ensure((size_t)mx * m->ld));
+  return SR_OK;
+}
+
+int check_model(const sr_model* m) {
+  if (!m) return fail(SR_EINVAL, "null model handle");
+  HIP_TRY(hipSetDevice(m->device));
+  return SR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sr_last_error(void) { return g_err; }
+
+int sr_device_count(int* count) {
+  if (!count) return fail(SR_EINVAL, "count is null");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { *count = 0; return fail(SR_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+  *count = n;
+  return SR_OK;
+}
+
+int sr_model_create(int device, uint32_t dim, uint32_t n_states, const uint32_t* dens_off, const double* means,
+                    const double* inv_vars, const double* norm, const double* logw, int max_approx, sr_model** out) {
+  if (!out) return fail(SR_EINVAL, "out is null");
+  *out = nullptr;
+  if (!dens_off || !means || !inv_vars || !norm || !logw) return fail(SR_EINVAL, "null model table");
+  if (dim == 0 || n_states == 0) return fail(SR_EINVAL, "dim and n_states must be positive");
+  const int ks = gmm_mfma_ksteps_for_dim(dim);
+  if (ks == 0) return fail(SR_ELIMIT, "dim %u unsupported (max 63)", dim);
+  if (dens_off[0] != 0) return fail(SR_EINVAL, "dens_off[0] must be 0");
+  for (uint32_t s = 0; s < n_states; s++)
+    if (dens_off[s + 1] < dens_off[s]) return fail(SR_EINVAL, "dens_off must be non-decreasing (state %u)", s);
+  const uint64_t C = dens_off[n_states];
+  if (C >= (1ull << 31)) return fail(SR_ELIMIT, "too many densities");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SR_ENODEV, "no HIP device visible");
+  if (device < 0 || device >= ndev) return fail(SR_EINVAL, "device %d out of range (0..%d)", device, ndev - 1);
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(SR_ENODEV, "device %d is %s; libsrgpu is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+  HIP_TRY(hipSetDevice(device));
+  sr_model* m = new sr_model();
+  m->device = device; m->dim = dim; m->n_states = n_states; m->n_dens = C; m->max_approx = max_approx != 0;
+  m->ksteps = ks;
+  m->ld = (n_states + 3u) & ~3u;
+  int rc = SR_OK;
+  do {
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&m->s_gmm, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&m->s_search, hipStreamNonBlocking)) != hipSuccess) {
+      rc = fail(SR_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+      break;
+    }
+    for (int i = 0; i < 2 && rc == SR_OK; i++) {
+      if ((e = hipEventCreateWithFlags(&m->ev_scored[i], hipEventDisableTiming)) != hipSuccess ||
+          (e = hipEventCreateWithFlags(&m->ev_consumed[i], hipEventDisableTiming)) != hipSuccess)
+        rc = fail(SR_EHIP, "hipEventCreate: %s", hipGetErrorString(e));
+    }
+    if (rc) break;
+    if ((e = m->dens_off.upload(dens_off, n_states + 1)) != hipSuccess || (e = m->means.upload(means, C * dim)) != hipSuccess ||
+        (e = m->inv_vars.upload(inv_vars, C * dim)) != hipSuccess || (e = m->norm.upload(norm, C)) != hipSuccess ||
+        (e = m->logw.upload(logw, C)) != hipSuccess) {
+      rc = fail(SR_EHIP, "model upload: %s", hipGetErrorString(e));
+      break;
+    }
+    rc = pack_model(m, dens_off, means, inv_vars, norm, logw);
+  } while (0);
+  if (rc != SR_OK) { sr_model_destroy(m); return rc; }
+  const char* env = getenv("SRGPU_SCORE_CHUNK_MB");
+  const size_t chunk_bytes = (env ? (size_t)atol(env) : 4096) << 20;
+  m->chunk_frames = std::max<size_t>(1, chunk_bytes / ((size_t)m->ld * sizeof(double)));
+  *out = m;
+  return SR_OK;
+}
+
+int sr_model_destroy(sr_model* m) {
+  if (!m) return SR_OK;
+  (void)hipSetDevice(m->device);
+  (void)hipDeviceSynchronize();
+  for (auto& ep : m->events) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+  m->dens_off.release(); m->means.release(); m->inv_vars.release(); m->norm.release(); m->logw.release();
+  m->apack.release(); m->blk_meta.release(); m->grp_state.release(); m->split_begin.release();
+  m->scores[0].release(); m->scores[1].release();
+  for (int i = 0; i < 2; i++) {
+    if (m->ev_scored[i]) (void)hipEventDestroy(m->ev_scored[i]);
+    if (m->ev_consumed[i]) (void)hipEventDestroy(m->ev_consumed[i]);
+  }
+  if (m->s_gmm) (void)hipStreamDestroy(m->s_gmm);
+  if (m->s_search) (void)hipStreamDestroy(m->s_search);
+  delete m;
+  return SR_OK;
+}
+
+int sr_model_info(const sr_model* m, uint32_t* dim, uint32_t* n_states, uint64_t* n_densities) {
+  if (!m) return fail(SR_EINVAL, "null model handle");
+  if (dim) *dim = m->dim;
+  if (n_states) *n_states = m->n_states;
+  if (n_densities) *n_densities = m->n_dens;
+  return SR_OK;
+}
+
+int sr_corpus_upload(sr_model* m, const float* feats, const uint64_t* frame_off, uint32_t n_utts, sr_corpus** out) {
+  if (!out) return fail(SR_EINVAL, "out is null");
+  *out = nullptr;
+  int rc = check_model(m);
+  if (rc) return rc;
+  if (!frame_off) return fail(SR_EINVAL, "frame_off is null");
+  if (frame_off[0] != 0) return fail(SR_EINVAL, "frame_off[0] must be 0");
+  for (uint32_t u = 0; u < n_utts; u++) {
+    if (frame_off[u + 1] < frame_off[u]) return fail(SR_EINVAL, "frame_off must be non-decreasing (utterance %u)", u);
+    if (frame_off[u + 1] - frame_off[u] > 65535)
+      return fail(SR_ELIMIT, "utterance %u has %llu frames; back pointers are 16 bit like the reference's Book::bkp (max 65535)",
+                  u, (unsigned long long)(frame_off[u + 1] - frame_off[u]));
+  }
+  const uint64_t F = frame_off[n_utts];
+  if (F > 0 && !feats) return fail(SR_EINVAL, "feats is null");
+  sr_corpus* c = new sr_corpus();
+  c->model = m; c->n_utts = n_utts; c->n_frames = F;
+  c->frame_off.assign(frame_off, frame_off + n_utts + 1);
+  hipError_t e;
+  if ((e = c->feats.ensure((size_t)F * m->dim + 64)) != hipSuccess ||
+      (F > 0 && (e = hipMemcpy(c->feats.p, feats, (size_t)F * m->dim * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) ||
+      (e = c->d_frame_off.upload(frame_off, n_utts + 1)) != hipSuccess) {
+    sr_corpus_destroy(c);
+    return fail(SR_EHIP, "corpus upload: %s", hipGetErrorString(e));
+  }
+  *out = c;
+  return SR_OK;
+}
+
+int sr_corpus_destroy(sr_corpus* c) {
+  if (!c) return SR_OK;
+  if (c->model) { (void)hipSetDevice(c->model->device); (void)hipDeviceSynchronize(); }
+  c->feats.release(); c->d_frame_off.release(); c->tb_score.release(); c->tb_word.release(); c->tb_bkp.release();
+  c->out_words.release(); c->out_count.release(); c->out_flags.release(); c->automata.release(); c->out_states.release();
+  c->aut_off.release(); c->bp_off.release(); c->backptr.release(); c->out_cost.release();
+  delete c;
+  return SR_OK;
+}
+
+int sr_score_corpus(sr_model* m, sr_corpus* c, int gmm_kernel, double* out) {
+  int rc = check_model(m);
+  if (rc) return rc;
+  if (!c || c->model != m) return fail(SR_EINVAL, "corpus does not belong to this model");
+  if (!out && c->n_frames) return fail(SR_EINVAL, "out is null");
+  // chunk over plain frame ranges; utterance boundaries do not matter for scoring
+  const uint64_t F = c->n_frames;
+  const size_t step = m->chunk_frames;
+  HIP_TRY(m->scores[0].ensure((size_t)std::min<uint64_t>(F, step) * m->ld));
+  for (uint64_t f = 0; f < F; f += step) {
+    const uint64_t n = std::min<uint64_t>(step, F - f);
+    if ((rc = launch_scoring(m, c->feats.p + f * m->dim, n, gmm_kernel, m->scores[0].p))) return rc;
+    HIP_TRY(hipStreamSynchronize(m->s_gmm));
+    HIP_TRY(hipMemcpy2D(out + f * m->n_states, (size_t)m->n_states * sizeof(double), m->scores[0].p,
+                        (size_t)m->ld * sizeof(double), (size_t)m->n_states * sizeof(double), (size_t)n,
+                        hipMemcpyDeviceToHost));
+  }
+  if (m->profiling) m->prof.frames += F;
+  return SR_OK;
+}
+
+int sr_score_frames(sr_model* m, const float* feats, uint64_t n_frames, int gmm_kernel, double* out) {
+  const uint64_t off[2] = {0, n_frames};
+  int rc = check_model(m);
+  if (rc) return rc;
+  // scoring has no 16-bit frame limit: bypass the per-utterance check by uploading directly
+  sr_corpus* c = new sr_corpus();
+  c->model = m; c->n_utts = 1; c->n_frames = n_frames; c->frame_off.assign(off, off + 2);
+  hipError_t e;
+  if ((e = c->feats.ensure((size_t)n_frames * m->dim + 64)) != hipSuccess ||
+      (n_frames > 0 && (e = hipMemcpy(c->feats.p, feats, (size_t)n_frames * m->dim * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)) {
+    sr_corpus_destroy(c);
+    return fail(SR_EHIP, "feature upload: %s", hipGetErrorString(e));
+  }
+  rc = sr_score_corpus(m, c, gmm_kernel, out);
+  sr_corpus_destroy(c);
+  return rc;
+}
+
+int sr_lexicon_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, const uint16_t* automaton,
+                      uint32_t silence_idx, const double tdp[3], uint16_t silence_state, sr_lexicon** out) {
+  if (!out) return fail(SR_EINVAL, "out is null");
+  *out = nullptr;
+  int rc = check_model(m);
+  if (rc) return rc;
+  if (!word_off || !automaton || !tdp) return fail(SR_EINVAL, "null lexicon table");
+  if (n_words == 0 || n_words > 65535) return fail(SR_ELIMIT, "n_words must be 1..65535 (Book::word is 16 bit)");
+  if (silence_idx >= n_words) return fail(SR_EINVAL, "silence_idx out of range");
+  if (word_off[0] != 0) return fail(SR_EINVAL, "word_off[0] must be 0");
+  uint32_t max_pos = 0;
+  for (uint32_t w = 0; w < n_words; w++) {
+    if (word_off[w + 1] <= word_off[w]) return fail(SR_EINVAL, "word %u has no positions", w);
+    max_pos = std::max(max_pos, word_off[w + 1] - word_off[w]);
+  }
+  // the reference addresses hypotheses as word*max_pos + pos and lets entry into position 1 alias the
+  // next word's position 0 when every word has a single position (Recognizer.cpp:139); not reproduced
+  if (max_pos < 2) return fail(SR_ELIMIT, "lexicon needs at least one word with two or more positions");
+  const uint32_t P = word_off[n_words];
+  if (P > decode_max_slots()) return fail(SR_ELIMIT, "%u trellis positions exceed the decoder's limit of %u", P, decode_max_slots());
+  std::vector<uint32_t> info(P), sword(P), wend(n_words);
+  for (uint32_t w = 0; w < n_words; w++) {
+    const uint32_t b = word_off[w], n = word_off[w + 1] - b;
+    const uint32_t first = automaton[b];
+    for (uint32_t k = 0; k < n; k++) {
+      const uint32_t st = automaton[b + k];
+      if (st >= m->n_states) return fail(SR_EINVAL, "word %u position %u: state %u >= n_states %u", w, k, st, m->n_states);
+      uint32_t f = st;
+      if (k == 0) f |= 1u << 16;
+      if (k == 1) f |= 1u << 17;
+      if (k == n - 1) f |= 1u << 18;
+      if (st == silence_state) f |= 1u << 19;
+      if (w == silence_idx) f |= 1u << 20;
+      if (first == silence_state) f |= 1u << 21;
+      if (n == 1) f |= 1u << 22;
+      info[b + k] = f;
+      sword[b + k] = w;
+    }
+    wend[w] = b + n - 1;
+  }
+  sr_lexicon* l = new sr_lexicon();
+  l->model = m; l->n_words = n_words; l->n_slots = P; l->silence_idx = silence_idx; l->silence_state = silence_state;
+  l->tdp[0] = tdp[0]; l->tdp[1] = tdp[1]; l->tdp[2] = tdp[2];
+  hipError_t e;
+  if ((e = l->slot_info.upload(info.data(), P)) != hipSuccess || (e = l->slot_word.upload(sword.data(), P)) != hipSuccess ||
+      (e = l->word_end_slot.upload(wend.data(), n_words)) != hipSuccess) {
+    sr_lexicon_destroy(l);
+    return fail(SR_EHIP, "lexicon upload: %s", hipGetErrorString(e));
+  }
+  *out = l;
+  return SR_OK;
+}
+
+int sr_lexicon_destroy(sr_lexicon* l) {
+  if (!l) return SR_OK;
+  if (l->model) { (void)hipSetDevice(l->model->device); (void)hipDeviceSynchronize(); }
+  l->slot_info.release(); l->slot_word.release(); l->word_end_slot.release();
+  delete l;
+  return SR_OK;
+}
+
+int sr_recognize_corpus(sr_model* m, sr_corpus* c, sr_lexicon* l, const sr_search_params* p, uint32_t* out_words,
+                        uint64_t* out_word_off, double* tb_score, uint16_t* tb_word, uint16_t* tb_bkp) {
+  int rc = check_model(m);
+  if (rc) return rc;
+  if (!c || c->model != m) return fail(SR_EINVAL, "corpus does not belong to this model");
+  if (!l || l->model != m) return fail(SR_EINVAL, "lexicon does not belong to this model");
+  if (!p || !out_word_off || (!out_words && c->n_frames)) return fail(SR_EINVAL, "null argument");
+  const uint32_t U = c->n_utts;
+  const uint64_t F = c->n_frames;
+  HIP_TRY(c->tb_score.ensure(F + U));
+  HIP_TRY(c->tb_word.ensure(F + U));
+  HIP_TRY(c->tb_bkp.ensure(F + U));
+  HIP_TRY(c->out_words.ensure(F));
+  HIP_TRY(c->out_count.ensure(U));
+  HIP_TRY(c->out_flags.ensure(U));
+  HIP_TRY(hipMemsetAsync(c->out_flags.p, 0, sizeof(uint32_t) * std::max(1u, U), m->s_search));
+  const std::vector<Chunk> chunks = make_chunks(c, m->chunk_frames);
+  if ((rc = ensure_score_ws(m, chunks))) return rc;
+
+  DecodeArgs da{};
+  da.net.n_slots = l->n_slots; da.net.n_words = l->n_words;
+  da.net.slot_info = l->slot_info.p; da.net.slot_word = l->slot_word.p; da.net.word_end_slot = l->word_end_slot.p;
+  da.net.silence_word = l->silence_idx; da.net.silence_state = l->silence_state;
+  da.net.tdp_loop = l->tdp[0]; da.net.tdp_forward = l->tdp[1]; da.net.tdp_skip = l->tdp[2];
+  da.ld = m->ld; da.frame_off = c->d_frame_off.p;
+  da.am_threshold = p->am_threshold; da.word_penalty = p->word_penalty;
+  da.tb_score = c->tb_score.p; da.tb_word = c->tb_word.p; da.tb_bkp = c->tb_bkp.p;
+  da.out_words = c->out_words.p; da.out_count = c->out_count.p; da.out_flags = c->out_flags.p;
+
+  // chunk i is scored on s_gmm into buffer i&1 while chunk i-1 is searched on s_search
+  for (size_t i = 0; i < chunks.size(); i++) {
+    const Chunk& ch = chunks[i];
+    const int buf = (int)(i & 1);
+    if (i >= 2) HIP_TRY(hipStreamWaitEvent(m->s_gmm, m->ev_consumed[buf], 0));
+    if ((rc = launch_scoring(m, c->feats.p + ch.f0 * m->dim, ch.f1 - ch.f0, p->gmm_kernel, m->scores[buf].p))) return rc;
+    HIP_TRY(hipEventRecord(m->ev_scored[buf], m->s_gmm));
+    HIP_TRY(hipStreamWaitEvent(m->s_search, m->ev_scored[buf], 0));
+    da.scores = m->scores[buf].p; da.frame_base = ch.f0; da.utt_first = ch.u0; da.n_utts = ch.u1 - ch.u0;
+    EventPair ep{};
+    if ((rc = prof_begin(m, m->s_search, 1, &ep))) return rc;
+    HIP_TRY(launch_decode(da, m->s_search));
+    if ((rc = prof_end(m, m->s_search, &ep))) return rc;
+    HIP_TRY(hipEventRecord(m->ev_consumed[buf], m->s_search));
+    if (m->profiling) m->prof.search_bytes += (8.0 * m->n_states + 4.0 * l->n_slots) * (double)(ch.f1 - ch.f0);
+  }
+  HIP_TRY(hipStreamSynchronize(m->s_search));
+  HIP_TRY(hipStreamSynchronize(m->s_gmm));
+
+  // gather results: words of utterance u start at out_words[frame_off[u]] on the device
+  std::vector<uint32_t> counts(U), dev_words(F);
+  if (U) HIP_TRY(hipMemcpy(counts.data(), c->out_count.p, sizeof(uint32_t) * U, hipMemcpyDeviceToHost));
+  if (F) HIP_TRY(hipMemcpy(dev_words.data(), c->out_words.p, sizeof(uint32_t) * F, hipMemcpyDeviceToHost));
+  uint64_t w = 0;
+  out_word_off[0] = 0;
+  for (uint32_t u = 0; u < U; u++) {
+    const uint64_t b = c->frame_off[u];
+    for (uint32_t i = 0; i < counts[u]; i++) out_words[w++] = dev_words[b + i];
+    out_word_off[u + 1] = w;
+  }
+  if (tb_score) HIP_TRY(hipMemcpy(tb_score, c->tb_score.p, sizeof(double) * (F + U), hipMemcpyDeviceToHost));
+  if (tb_word) HIP_TRY(hipMemcpy(tb_word, c->tb_word.p, sizeof(uint16_t) * (F + U), hipMemcpyDeviceToHost));
+  if (tb_bkp) HIP_TRY(hipMemcpy(tb_bkp, c->tb_bkp.p, sizeof(uint16_t) * (F + U), hipMemcpyDeviceToHost));
+  if (m->profiling) m->prof.frames += F;
+  return SR_OK;
+}
+
+int sr_recognize_batch(sr_model* m, sr_lexicon* l, const sr_search_params* p, const float* feats,
+                       const uint64_t* frame_off, uint32_t n_utts, uint32_t* out_words, uint64_t* out_word_off) {
+  sr_corpus* c = nullptr;
+  int rc = sr_corpus_upload(m, feats, frame_off, n_utts, &c);
+  if (rc) return rc;
+  rc = sr_recognize_corpus(m, c, l, p, out_words, out_word_off, nullptr, nullptr, nullptr);
+  sr_corpus_destroy(c);
+  return rc;
+}
+
+static int align_common(sr_model* m, sr_corpus* c, const uint16_t* automata, const uint64_t* aut_off, const double tdp[3],
+                        uint16_t silence_state, double thr, bool pruned, int gmm_kernel, uint16_t* out_states,
+                        double* out_cost) {
+  int rc = check_model(m);
+  if (rc) return rc;
+  if (!c || c->model != m) return fail(SR_EINVAL, "corpus does not belong to this model");
+  if (!automata || !aut_off || !tdp || !out_states || !out_cost) return fail(SR_EINVAL, "null argument");
+  const uint32_t U = c->n_utts;
+  const uint64_t F = c->n_frames;
+  std::vector<uint64_t> bp_off(U + 1, 0);
+  uint32_t max_n = 1;
+  for (uint32_t u = 0; u < U; u++) {
+    const uint64_t N = aut_off[u + 1] - aut_off[u], T = c->frame_off[u + 1] - c->frame_off[u];
+    if (N < 1 || T < 1) return fail(SR_EINVAL, "utterance %u: automaton and utterance must be non-empty", u);
+    if (!pruned && N > T)
+      return fail(SR_EINVAL, "utterance %u: automaton length %llu exceeds %llu frames (Aligner::align_sequence_full indexes "
+                  "its T-sized cost arrays by position)", u, (unsigned long long)N, (unsigned long long)T);
+    if (N > align_max_positions()) return fail(SR_ELIMIT, "utterance %u: automaton length %llu exceeds %u", u, (unsigned long long)N, align_max_positions());
+    for (uint64_t i = aut_off[u]; i < aut_off[u + 1]; i++)
+      if (automata[i] >= m->n_states) return fail(SR_EINVAL, "utterance %u: automaton state %u >= n_states", u, automata[i]);
+    max_n = std::max<uint32_t>(max_n, (uint32_t)N);
+    bp_off[u + 1] = bp_off[u] + N * T;
+  }
+  HIP_TRY(c->automata.upload(automata, aut_off[U]));
+  HIP_TRY(c->aut_off.upload(aut_off, U + 1));
+  HIP_TRY(c->bp_off.upload(bp_off.data(), U + 1));
+  HIP_TRY(c->backptr.ensure(bp_off[U]));
+  HIP_TRY(c->out_states.ensure(F));
+  HIP_TRY(c->out_cost.ensure(U));
+  const std::vector<Chunk> chunks = make_chunks(c, m->chunk_frames);
+  if ((rc = ensure_score_ws(m, chunks))) return rc;
+  AlignArgs aa{};
+  aa.ld = m->ld; aa.frame_off = c->d_frame_off.p; aa.automata = c->automata.p; aa.aut_off = c->aut_off.p;
+  aa.tdp_loop = tdp[0]; aa.tdp_forward = tdp[1]; aa.tdp_skip = tdp[2]; aa.silence_state = silence_state;
+  aa.pruning_threshold = thr; aa.backptr = c->backptr.p; aa.bp_off = c->bp_off.p; aa.max_positions = max_n;
+  aa.out_states = c->out_states.p; aa.out_cost = c->out_cost.p;
+  for (size_t i = 0; i < chunks.size(); i++) {
+    const Chunk& ch = chunks[i];
+    const int buf = (int)(i & 1);
+    if (i >= 2) HIP_TRY(hipStreamWaitEvent(m->s_gmm, m->ev_consumed[buf], 0));
+    if ((rc = launch_scoring(m, c->feats.p + ch.f0 * m->dim, ch.f1 - ch.f0, gmm_kernel, m->scores[buf].p))) return rc;
+    HIP_TRY(hipEventRecord(m->ev_scored[buf], m->s_gmm));
+    HIP_TRY(hipStreamWaitEvent(m->s_search, m->ev_scored[buf], 0));
+    aa.scores = m->scores[buf].p; aa.frame_base = ch.f0; aa.utt_first = ch.u0; aa.n_utts = ch.u1 - ch.u0;
+    EventPair ep{};
+    if ((rc = prof_begin(m, m->s_search, 1, &ep))) return rc;
+    HIP_TRY(pruned ? launch_align_pruned(aa, m->s_search) : launch_align_full(aa, m->s_search));
+    if ((rc = prof_end(m, m->s_search, &ep))) return rc;
+    HIP_TRY(hipEventRecord(m->ev_consumed[buf], m->s_search));
+  }
+  HIP_TRY(hipStreamSynchronize(m->s_search));
+  HIP_TRY(hipStreamSynchronize(m->s_gmm));
+  if (F) HIP_TRY(hipMemcpy(out_states, c->out_states.p, sizeof(uint16_t) * F, hipMemcpyDeviceToHost));
+  if (U) HIP_TRY(hipMemcpy(out_cost, c->out_cost.p, sizeof(double) * U, hipMemcpyDeviceToHost));
+  if (m->profiling) {
+    m->prof.frames += F;
+    for (uint32_t u = 0; u < U; u++) m->prof.search_bytes += 9.0 * (double)bp_off[u + 1] - 9.0 * (double)bp_off[u];
+  }
+  return SR_OK;
+}
+
+int sr_align_corpus(sr_model* m, sr_corpus* c, const uint16_t* automata, const uint64_t* aut_off, const double tdp[3],
+                    uint16_t silence_state, int gmm_kernel, uint16_t* out_states, double* out_cost) {
+  return align_common(m, c, automata, aut_off, tdp, silence_state, 0.0, false, gmm_kernel, out_states, out_cost);
+}
+
+int sr_align_corpus_pruned(sr_model* m, sr_corpus* c, const uint16_t* automata, const uint64_t* aut_off,
+                           const double tdp[3], uint16_t silence_state, double pruning_threshold, int gmm_kernel,
+                           uint16_t* out_states, double* out_cost) {
+  return align_common(m, c, automata, aut_off, tdp, silence_state, pruning_threshold, true, gmm_kernel, out_states, out_cost);
+}
+
+int sr_profile_enable(sr_model* m, int on) {
+  if (!m) return fail(SR_EINVAL, "null model handle");
+  m->profiling = on != 0;
+  return SR_OK;
+}
+
+int sr_profile_reset(sr_model* m) {
+  int rc = check_model(m);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  for (auto& ep : m->events) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+  m->events.clear();
+  m->prof = sr_profile{};
+  return SR_OK;
+}
+
+int sr_profile_read(sr_model* m, sr_profile* out) {
+  int rc = check_model(m);
+  if (rc) return rc;
+  if (!out) return fail(SR_EINVAL, "out is null");
+  HIP_TRY(hipDeviceSynchronize());
+  for (auto& ep : m->events) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ep.a, ep.b));
+    if (ep.kind == 0) { m->prof.gmm_ms += ms; m->prof.gmm_launches++; }
+    else { m->prof.search_ms += ms; m->prof.search_launches++; }
+    (void)hipEventDestroy(ep.a);
+    (void)hipEventDestroy(ep.b);
+  }
+  m->events.clear();
+  *out = m->prof;
+  return SR_OK;
+}
+
+}  // extern "C"

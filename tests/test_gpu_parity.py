@@ -1,0 +1,256 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the C ABI
+(speechrecognition_amd/capi.py -> libsrgpu.so), against the golden vectors the real reference
+produced and against the CPU oracle on the same seeded inputs.
+
+Tolerances: integer/index results (words, state sequences, back pointers) bit-exact; SR_GMM_EXACT
+scores bit-exact; SR_GMM_MFMA scores within 1e-9 relative (north_star asks 1e-4; the FP64 GEMM form
+is good to ~1e-13)."""
+import numpy as np
+import pytest
+
+from speechrecognition_amd import capi, synth
+from tests.util import Case, golden_names
+
+pytestmark = pytest.mark.gpu
+
+MFMA_RTOL = 1e-9
+
+
+def _assert_scores_close(got, want, rtol=MFMA_RTOL):
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin)
+    denom = np.maximum(np.abs(want[fin]), 1.0)
+    err = np.abs(got[fin] - want[fin]) / denom
+    assert err.max(initial=0.0) <= rtol, f"max rel err {err.max():.3e}"
+
+
+def _lex_handle(model, c):
+    word_off, automaton, sil_state = c.lex.flatten()
+    return model.lexicon(word_off, automaton, c.lex.silence_idx, c.tdp, sil_state), sil_state
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_scores(name, tmp_path):
+    c = Case(name, tmp_path)
+    with capi.Model.from_mixset(c.mixset_path, c.dim, c.pooling, c.max_approx) as m:
+        exact = m.score_frames(c.feats, capi.GMM_EXACT)
+        mfma = m.score_frames(c.feats, capi.GMM_MFMA)
+    if c.max_approx:
+        c.check_scores(exact, exact=True)  # bit-identical to MixtureModel::score
+    else:
+        c.check_scores(exact, exact=False, rtol=1e-12)  # sum mode: device exp/log
+    want = c.z["scores"] if "scores" in c.z else None
+    if want is not None:
+        _assert_scores_close(mfma, want)
+    else:
+        _assert_scores_close(mfma.reshape(-1)[c.z["score_idx"]], c.z["score_val"])
+
+
+@pytest.mark.parametrize("kernel", [capi.GMM_EXACT, capi.GMM_MFMA])
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_decode_and_align(name, kernel, tmp_path, oracle_lib):
+    c = Case(name, tmp_path)
+    T = c.feats.shape[0]
+    off = np.array([0, T], dtype=np.uint64)
+    with capi.Model.from_mixset(c.mixset_path, c.dim, c.pooling, c.max_approx) as m:
+        lex, sil_state = _lex_handle(m, c)
+        corpus = m.upload(c.feats, off)
+        words, woff, (tbs, tbw, tbb) = corpus.recognize(lex, c.beam, c.wp, kernel, traceback=True)
+        assert np.array_equal(words, c.z["words"]), (words, c.z["words"])
+        assert woff[-1] == len(c.z["words"])
+        # traceback array against the oracle's (scores bit-exact only with the exact kernel)
+        o = c.oracle(oracle_lib)
+        _, (os_, ow, ob) = o.decode(c.feats, traceback=True)
+        o.close()
+        assert np.array_equal(tbw, ow) and np.array_equal(tbb, ob)
+        if kernel == capi.GMM_EXACT and c.max_approx:
+            assert np.array_equal(tbs.view(np.uint64), os_.view(np.uint64))
+        else:
+            _assert_scores_close(tbs, os_)
+        if "align_ref" in c.z:
+            st, cost = corpus.align([c.z["align_ref"]], c.tdp, sil_state, kernel)
+            assert np.array_equal(st, c.z["align_full_states"])
+            if kernel == capi.GMM_EXACT and c.max_approx:
+                assert cost[0] == float(c.z["align_full_cost"])
+            else:
+                assert abs(cost[0] - float(c.z["align_full_cost"])) <= MFMA_RTOL * max(1.0, abs(float(c.z["align_full_cost"])))
+            i = 0
+            while f"align_pruned_thr{i}" in c.z:
+                st, cost = corpus.align([c.z["align_ref"]], c.tdp, sil_state, kernel,
+                                        pruning_threshold=float(c.z[f"align_pruned_thr{i}"]))
+                assert np.array_equal(st, c.z[f"align_pruned_states{i}"])
+                want = float(c.z[f"align_pruned_cost{i}"])
+                if kernel == capi.GMM_EXACT and c.max_approx:
+                    assert cost[0] == want
+                else:
+                    assert abs(cost[0] - want) <= MFMA_RTOL * max(1.0, abs(want))
+                i += 1
+        corpus.close()
+        lex.close()
+
+
+def _random_setup(tmp_path, seed, W, spw, reps, M, D, var_floor=0.5):
+    lex = synth.make_lexicon(W, spw, reps)
+    rng = np.random.default_rng(seed)
+    nm = M if np.isscalar(M) else rng.integers(M[0], M[1] + 1, size=lex.n_states)
+    spec = synth.make_mixset(lex.n_states, nm, D, seed=seed, var_floor=var_floor)
+    mp = str(tmp_path / f"m{seed}.mix")
+    synth.write_mixset(mp, spec)
+    return lex, spec, mp
+
+
+@pytest.mark.parametrize("seed,W,spw,reps,M,D,beam", [
+    (201, 40, 3, 1, (1, 6), 39, 200.0),    # ragged mixture sizes -> padded 4-state groups
+    (202, 25, 4, 2, 3, 25, 40.0),          # D = 25 (KSTEPS 14), repetitions 2
+    (203, 10, 3, 1, 5, 12, 30.0),          # D = 12 (KSTEPS 8)
+    (204, 15, 3, 1, 2, 50, 100.0),         # D = 50 (KSTEPS 32, generic-dim exact kernel)
+    (205, 200, 3, 1, 4, 39, 150.0),        # P = 601 -> 4 slots per thread
+    (206, 700, 3, 1, 2, 39, 200.0),        # P = 2101 -> 1024 threads x 4
+])
+def test_batch_vs_oracle(tmp_path, oracle_lib, seed, W, spw, reps, M, D, beam):
+    """A ragged batch (including a 1-frame utterance) through score + decode + align, vs the oracle."""
+    lex, spec, mp = _random_setup(tmp_path, seed, W, spw, reps, M, D)
+    o = oracle_lib.Oracle(mp, D, lex, am_threshold=beam)
+    rng = np.random.default_rng(seed + 1)
+    lens = [1, 2] + list(rng.integers(30, 90, size=6))
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    feats = rng.standard_normal((int(off[-1]), D)).astype(np.float32)
+    # two utterances drawn from the model so that the beam prunes like on speech
+    u4 = synth.sample_utterance(spec, lex, rng.integers(1, lex.n_words, size=3), seed=seed + 2)[: lens[4]]
+    feats[int(off[4]):int(off[4]) + len(u4)] = u4
+    word_off, automaton, sil_state = lex.flatten()
+    with capi.Model.from_mixset(mp, D) as m:
+        lexh = m.lexicon(word_off, automaton, lex.silence_idx, (3.0, 0.0, 30.0), sil_state)
+        corpus = m.upload(feats, off)
+        want = o.score_matrix(feats)
+        got_exact = corpus.score(capi.GMM_EXACT)
+        assert np.array_equal(got_exact.view(np.uint64), want.view(np.uint64))
+        _assert_scores_close(corpus.score(capi.GMM_MFMA), want)
+        for kernel in (capi.GMM_EXACT, capi.GMM_MFMA):
+            words, woff = corpus.recognize(lexh, beam, 10.0, kernel)
+            for u in range(len(lens)):
+                w = o.decode(feats[int(off[u]):int(off[u + 1])])
+                assert np.array_equal(w, words[int(woff[u]):int(woff[u + 1])]), (u, kernel)
+        # aligner: utterances long enough for `sil w sil w sil`
+        auts, keep = [], []
+        for u in range(len(lens)):
+            ws = rng.integers(1, lex.n_words, size=2)
+            a = [sil_state]
+            for w in ws:
+                a += list(automaton[word_off[w]:word_off[w + 1]]) + [sil_state]
+            if len(a) > lens[u]:
+                a = [sil_state]
+            auts.append(np.asarray(a, dtype=np.uint16))
+        st, cost = corpus.align(auts, (3.0, 0.0, 30.0), sil_state, capi.GMM_EXACT)
+        stp, costp = corpus.align(auts, (3.0, 0.0, 30.0), sil_state, capi.GMM_EXACT, pruning_threshold=25.0)
+        for u in range(len(lens)):
+            f = feats[int(off[u]):int(off[u + 1])]
+            ws, wc = o.align_full(f, auts[u])
+            assert np.array_equal(st[int(off[u]):int(off[u + 1])], ws) and (cost[u] == wc or (np.isinf(wc) and np.isinf(cost[u])))
+            ws, wc = o.align_pruned(f, auts[u], 25.0)
+            assert np.array_equal(stp[int(off[u]):int(off[u + 1])], ws) and costp[u] == wc
+        corpus.close()
+        lexh.close()
+    o.close()
+
+
+def test_negative_emission_costs_take_the_sequential_path(tmp_path, oracle_lib):
+    """Tight variances make emission costs negative, where the reference's pre-AM early-out
+    (Recognizer.cpp:143,173) is live: the decoder must replay it, not shortcut it."""
+    lex = synth.make_lexicon(30, 3, 2)
+    spec = synth.make_mixset(lex.n_states, 2, 39, seed=301, var_floor=0.002)
+    mu = spec.mean_acc / spec.mean_w[:, None]
+    var = 0.004 * (spec.var_acc / spec.var_w[:, None] - mu ** 2)
+    spec.var_acc = (var + mu ** 2) * spec.var_w[:, None]
+    mp = str(tmp_path / "neg.mix")
+    synth.write_mixset(mp, spec)
+    rng = np.random.default_rng(302)
+    utts = [synth.sample_utterance(spec, lex, rng.integers(1, lex.n_words, size=4), seed=310 + i, frames_per_state=(1, 3), noise=0.8)
+            for i in range(6)]
+    off = np.concatenate([[0], np.cumsum([len(x) for x in utts])]).astype(np.uint64)
+    feats = np.concatenate(utts)
+    word_off, automaton, sil_state = lex.flatten()
+    for beam, wp in ((150.0, 2.0), (40.0, 0.0)):
+        o = oracle_lib.Oracle(mp, 39, lex, am_threshold=beam, word_penalty=wp)
+        assert (o.score_matrix(feats) < 0).any()
+        with capi.Model.from_mixset(mp, 39) as m:
+            lexh = m.lexicon(word_off, automaton, lex.silence_idx, (3.0, 0.0, 30.0), sil_state)
+            corpus = m.upload(feats, off)
+            words, woff, (tbs, tbw, tbb) = corpus.recognize(lexh, beam, wp, capi.GMM_EXACT, traceback=True)
+            for u in range(len(utts)):
+                w, (os_, ow, ob) = o.decode(utts[u], traceback=True)
+                assert np.array_equal(w, words[int(woff[u]):int(woff[u + 1])])
+                b = int(off[u]) + u
+                assert np.array_equal(tbs[b:b + len(os_)].view(np.uint64), os_.view(np.uint64))
+                assert np.array_equal(tbw[b:b + len(ow)], ow) and np.array_equal(tbb[b:b + len(ob)], ob)
+            corpus.close()
+            lexh.close()
+        o.close()
+
+
+def test_chunked_pipeline_matches_single_chunk(tmp_path, oracle_lib, monkeypatch):
+    """A tiny score-workspace budget forces many chunks through the two-stream pipeline."""
+    lex, spec, mp = _random_setup(tmp_path, 401, 60, 3, 1, 4, 39)
+    feats, off = synth.make_batch(40, 20, 60, 39, seed=402)
+    word_off, automaton, sil_state = lex.flatten()
+    results = []
+    for mb in ("4096", "1"):
+        monkeypatch.setenv("SRGPU_SCORE_CHUNK_MB", mb)
+        with capi.Model.from_mixset(mp, 39) as m:
+            lexh = m.lexicon(word_off, automaton, lex.silence_idx, (3.0, 0.0, 30.0), sil_state)
+            corpus = m.upload(feats, off)
+            results.append((corpus.recognize(lexh, 200.0, 10.0, capi.GMM_MFMA), corpus.score(capi.GMM_MFMA)))
+            corpus.close()
+            lexh.close()
+    (w0, o0), s0 = results[0]
+    (w1, o1), s1 = results[1]
+    assert np.array_equal(w0, w1) and np.array_equal(o0, o1) and np.array_equal(s0.view(np.uint64), s1.view(np.uint64))
+    o = oracle_lib.Oracle(mp, 39, lex, am_threshold=200.0)
+    for u in (0, 17, 39):
+        assert np.array_equal(o.decode(feats[int(off[u]):int(off[u + 1])]), w0[int(o0[u]):int(o0[u + 1])])
+    o.close()
+
+
+def test_full_size_properties(tmp_path):
+    """BASELINE.json configs[2] model size (4000 states x 32 mixtures = 128000 densities, beyond what
+    the reference's 16-bit density index can load): size-independent properties instead of an oracle run.
+      * MFMA scores == EXACT scores to 1e-9 relative on a frame sample,
+      * permuting utterances permutes results (independence / sharding invariance),
+      * decoding the concatenated batch equals decoding each half (chunk invariance)."""
+    lex = synth.make_lexicon(1333, 3, 1)
+    spec = synth.make_mixset(lex.n_states, 32, 39, seed=23)
+    mp = str(tmp_path / "big.mix")
+    synth.write_mixset(mp, spec)
+    feats, off = synth.make_batch(24, 200, 400, 39, seed=7)
+    word_off, automaton, sil_state = lex.flatten()
+    with capi.Model.from_mixset(mp, 39) as m:
+        assert m.n_densities == 128000
+        lexh = m.lexicon(word_off, automaton, lex.silence_idx, (3.0, 0.0, 30.0), sil_state)
+        sample = feats[:300]
+        _assert_scores_close(m.score_frames(sample, capi.GMM_MFMA), m.score_frames(sample, capi.GMM_EXACT))
+        corpus = m.upload(feats, off)
+        words, woff = corpus.recognize(lexh, 200.0, 10.0, capi.GMM_MFMA)
+        wexact, woff_exact = corpus.recognize(lexh, 200.0, 10.0, capi.GMM_EXACT)
+        assert np.array_equal(words, wexact) and np.array_equal(woff, woff_exact)
+        corpus.close()
+        per_utt = [words[int(woff[u]):int(woff[u + 1])] for u in range(24)]
+        assert sum(len(x) for x in per_utt) > 0
+        perm = np.random.default_rng(5).permutation(24)
+        pf = np.concatenate([feats[int(off[u]):int(off[u + 1])] for u in perm])
+        poff = np.concatenate([[0], np.cumsum([int(off[u + 1] - off[u]) for u in perm])]).astype(np.uint64)
+        c2 = m.upload(pf, poff)
+        w2, o2 = c2.recognize(lexh, 200.0, 10.0, capi.GMM_MFMA)
+        c2.close()
+        for i, u in enumerate(perm):
+            assert np.array_equal(w2[int(o2[i]):int(o2[i + 1])], per_utt[u])
+        lexh.close()
+
+
+def test_error_paths():
+    with pytest.raises(capi.SrError) as e:
+        capi.Model.from_mixset("/nonexistent.mix", 39)
+    assert e.value.code == -1 and "cannot open" in str(e.value)
+    means = np.zeros((2, 70))
+    with pytest.raises(capi.SrError) as e:
+        capi.Model.from_tables([0, 1, 2], means, means + 1, np.zeros(2), np.zeros(2))
+    assert e.value.code == -4  # dim > 63
