@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s scored + decoded on MI355X for BASELINE.json's headline configuration.
+
+Workload (BASELINE.json configs[2]): 4000 tied states (silence + 1333 three-state words),
+32-mixture diagonal GMM (128 000 densities), 39-dim float32 features, a batch of 1000 synthetic
+utterances (lengths U{200..400}, i.i.d. N(0,1) frames) PER GPU, beam (am-threshold) 200, word penalty 10,
+TDP 3/0/30.  A "step" is one full pass over the resident batch: dense GMM scoring of every frame
+(FP64 MFMA kernel) + beam Viterbi decode of every utterance + recognised words back on the host.
+Features are resident in HBM before the timed region (sr_corpus_upload); results leave the device
+inside it.
+
+Multi-GPU: one process per GPU (torchrun), each rank decodes its own shard of utterances with a full
+model replica; there is no data-path collective (utterances are independent, Recognizer.cpp:46-47).
+torch.distributed is used only for the barrier and the max-over-ranks of the step time.
+
+Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (GMM kernel, timed with
+HIP events on its launch stream by libsrgpu's sr_profile_*) and, at N=1, `cpu_baseline` (the CPU oracle's
+Recognizer::recognize loop on a bounded sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD's MI355X FP64 matrix figure; the local guide has no FP64 row
+FRAME_SHIFT_S = 0.010         # 10 ms frames (sietill/SignalAnalysis.cpp:49, Corpus.cpp:92)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--utts", type=int, default=1000, help="utterances per GPU")
+    ap.add_argument("--words", type=int, default=1333, help="three-state words (states = 1 + 3*words)")
+    ap.add_argument("--mix", type=int, default=32)
+    ap.add_argument("--beam", type=float, default=200.0)
+    ap.add_argument("--kernel", choices=["mfma", "exact"], default="mfma")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget of the cpu_baseline leg")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from speechrecognition_amd import capi, synth
+
+    D = 39
+    lex = synth.make_lexicon(args.words, 3, 1)
+    S = lex.n_states
+    tdp, wp = (3.0, 0.0, 30.0), 10.0
+    tmp = tempfile.mkdtemp(prefix=f"srbench{rank}_")
+    mixset_path = os.path.join(tmp, "model.mix")
+    spec = synth.make_mixset(S, args.mix, D, seed=23)       # same model on every rank (replicated, read-only)
+    synth.write_mixset(mixset_path, spec)
+    feats, frame_off = synth.make_batch(args.utts, 200, 400, D, seed=7 + 1000 * rank)  # this rank's shard
+    n_frames = int(frame_off[-1])
+    word_off, automaton, sil_state = lex.flatten()
+    kernel = capi.GMM_MFMA if args.kernel == "mfma" else capi.GMM_EXACT
+
+    model = capi.Model.from_mixset(mixset_path, D, capi.POOL_NONE, True, device=local_rank)
+    lexh = model.lexicon(word_off, automaton, lex.silence_idx, tdp, sil_state)
+    corpus = model.upload(feats, frame_off)  # inputs resident in HBM before timing starts
+
+    def step():
+        return corpus.recognize(lexh, args.beam, wp, kernel)
+
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        words, woff = step()
+    model.profile(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        words, woff = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = model.profile_read()
+    model.profile(False)
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        fr = torch.tensor([n_frames], dtype=torch.float64, device="cuda")
+        dist.all_reduce(fr, op=dist.ReduceOp.SUM)
+        total_frames = float(fr.item())
+    else:
+        total_frames = float(n_frames)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_frames * args.steps / elapsed
+        gmm_s = prof["gmm_ms"] * 1e-3
+        achieved = prof["gmm_flops"] / gmm_s / 1e12 if gmm_s > 0 else 0.0
+        out = {
+            "metric": "frames/sec scored+decoded",
+            "value": value,
+            "unit": "frames/s",
+            "xRT": value * FRAME_SHIFT_S,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{S} states x {args.mix}-mix diag GMM ({S * args.mix} densities), 39-d float32 frames, "
+                            f"{args.utts} utterances/GPU U{{200..400}} frames, beam {args.beam:g}, dense scoring + beam Viterbi",
+                "states": S, "mixtures": args.mix, "feat_dim": D, "utterances_per_gpu": args.utts,
+                "frames_per_gpu_rank0": n_frames, "words": lex.n_words, "trellis_positions": int(word_off[-1]),
+                "gmm_kernel": args.kernel, "parallelism": f"utterance-shard x{world}, no collective",
+            },
+            "roofline": {
+                "kernel": "gmm_mfma_kernel" if args.kernel == "mfma" else "gmm_exact_kernel",
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": FP64_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                "traffic": None,
+                "launches": prof["gmm_launches"],
+                "avg_launch_ms": prof["gmm_ms"] / max(1, prof["gmm_launches"]),
+                "flops_per_frame": 4.0 * D * S * args.mix,
+            },
+            "search": {
+                "kernel": "decode_kernel",
+                "bound": "hbm",
+                "ms_per_step": prof["search_ms"] / args.steps,
+                "achieved_GBps": prof["search_bytes"] / (prof["search_ms"] * 1e-3) / 1e9 if prof["search_ms"] > 0 else 0.0,
+                "bytes_per_frame": 8.0 * S + 4.0 * int(word_off[-1]),
+            },
+            "recognised_words_rank0": int(woff[-1]),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, mixset_path, lex, tdp, wp, feats, frame_off, words, woff)
+        print(json.dumps(out))
+        sys.stdout.flush()
+
+    corpus.close()
+    lexh.close()
+    model.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, mixset_path, lex, tdp, wp, feats, frame_off, gpu_words, gpu_woff):
+    """The CPU oracle's utterance loop (the reference's timed region, Recognizer.cpp:45-80) with the
+    reference's strategy (OpenMP over utterances, :46) on a bounded sample of the same batch; the
+    sample's words are also checked against the GPU's."""
+    from oracle import pyoracle
+
+    cores = len(os.sched_getaffinity(0))
+    orc = pyoracle.Oracle(mixset_path, 39, lex, tdp=tdp, am_threshold=args.beam, word_penalty=wp)
+    # calibrate on one short utterance, single thread
+    lens = np.diff(frame_off.astype(np.int64))
+    u0 = int(np.argmin(lens))
+    f0 = feats[int(frame_off[u0]):int(frame_off[u0 + 1])]
+    t = time.perf_counter()
+    orc.decode(f0)
+    per_frame = (time.perf_counter() - t) / max(1, len(f0))
+    budget_frames = args.cpu_seconds * cores / max(per_frame, 1e-9)
+    n = int(np.searchsorted(frame_off[1:].astype(np.float64), budget_frames)) + 1
+    n = max(min(n, len(lens)), min(cores, len(lens)))
+    sub_off = frame_off[: n + 1].copy()
+    sub_feats = feats[: int(sub_off[-1])]
+    words, woff, secs = orc.recognize_batch(sub_feats, sub_off, n_threads=cores)
+    match = bool(np.array_equal(words, gpu_words[: int(gpu_woff[n])]) and np.array_equal(woff, gpu_woff[: n + 1]))
+    fps = float(sub_off[-1]) / secs
+    orc.close()
+    return {
+        "value": fps,
+        "unit": "frames/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"first {n} of {len(lens)} utterances ({int(sub_off[-1])} frames), lazy scoring + beam {args.beam:g}, "
+                  f"OpenMP schedule(dynamic) over utterances, {secs:.1f} s wall",
+        "words_match_gpu": match,
+    }
+
+
+if __name__ == "__main__":
+    main()
