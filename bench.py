@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--beam", type=float, default=200.0)
     ap.add_argument("--kernel", choices=["mfma", "exact"], default="mfma")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="CPU work budget of the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the cpu_baseline leg")
     return ap.parse_args()
 
 
@@ -172,13 +172,26 @@ def main():
         dist.destroy_process_group()
 
 
+def usable_cores():
+    """Threads we may really use: the cgroup CPU quota if there is one, else the affinity mask, and never
+    more than 16 (the GPU box gives one GPU's job a 16-CPU share)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(args, mixset_path, lex, tdp, wp, feats, frame_off, gpu_words, gpu_woff):
     """The CPU oracle's utterance loop (the reference's timed region, Recognizer.cpp:45-80) with the
     reference's strategy (OpenMP over utterances, :46) on a bounded sample of the same batch; the
     sample's words are also checked against the GPU's."""
     from oracle import pyoracle
 
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     orc = pyoracle.Oracle(mixset_path, 39, lex, tdp=tdp, am_threshold=args.beam, word_penalty=wp)
     # calibrate on one short utterance, single thread
     lens = np.diff(frame_off.astype(np.int64))

@@ -28,6 +28,7 @@
 // score rows and two workgroup barriers per frame.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "kernels.h"
 
@@ -44,39 +45,105 @@ static constexpr uint32_t kSlotSingle = 1u << 22;    // one-position word: owns 
 
 static constexpr double kInf = __builtin_huge_val();
 
+// Diagnostic build only (-DSR_DECODE_STAMPS): per-phase cycle sums of wave 0, written over traceback
+// scores 1..6 of the utterance at the end.  Never defined in the shipped library.
+#ifdef SR_DECODE_STAMPS
+#define SR_STAMP(k)                                                                     \
+  do {                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                       \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                 \
+    stamp_sum[k] += now_ - stamp_last;                                                  \
+    stamp_last = now_;                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                  \
+  } while (0)
+#else
+#define SR_STAMP(k) do {} while (0)
+#endif
+
 struct Merge {  // one target hypothesis being built (Book, Recognizer.hpp:75-89; word/pos are static)
   double score;
   uint32_t bkp;
   __device__ Merge() : score(kInf), bkp(0) {}
   // Recognizer.cpp:143-157 / :173-186
   __device__ void offer(double pre_am, double am, uint32_t cand_bkp) {
-    if (pre_am > score) return;
     const double n = pre_am + am;
-    if (score > n) { score = n; bkp = cand_bkp; }
+    const bool take = !(pre_am > score) && (score > n);  // `continue` on the early-out, then strict improvement
+    score = take ? n : score;
+    bkp = take ? cand_bkp : bkp;
   }
 };
 
-__device__ inline double shfl_xor_f64(double v, int m) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __shfl_xor(lo, m);
-  hi = __shfl_xor(hi, m);
-  return __hiloint2double(hi, lo);
+// (value, index) lexicographic minimum across the wave: every lane ends with the result
+__device__ inline void wave_min_idx(double& v, uint32_t& idx) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    const int lo = __shfl_xor(__double2loint(v), m), hi = __shfl_xor(__double2hiint(v), m);
+    const double ov = __hiloint2double(hi, lo);
+    const uint32_t oi = __shfl_xor(idx, m);
+    if (ov < v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+  }
+}
+__device__ inline double wave_min(double v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    const int lo = __shfl_xor(__double2loint(v), m), hi = __shfl_xor(__double2hiint(v), m);
+    const double ov = __hiloint2double(hi, lo);
+    v = ov < v ? ov : v;
+  }
+  return v;
 }
 
-template <int SPT, int NTMAX>
-__global__ __launch_bounds__(NTMAX) void decode_kernel(DecodeArgs a) {
+// Sequential replay of the word-boundary loop (Recognizer.cpp:133-158) for ONE target slot whose
+// candidates involve a negative emission cost: sources in ascending slot order -- word ends of the
+// words before this one, the in-word sources, then the remaining word ends.  Rare; reached only through a
+// wave-uniform branch.
+__device__ inline Merge replay_boundary(const uint32_t* word_end_slot, uint32_t W, const double* sc,
+                                                           const uint16_t* bk, uint32_t p, bool pos1, bool has_loop,
+                                                           bool in_word, double wp, double t_b, double am_b, double am,
+                                                           double t_fwd, double t_loop, uint32_t bkp_new) {
+  Merge mg;
+  const uint32_t base = pos1 ? p - 1 : p;  // slot of position 0 of this word
+  uint32_t v = 0;
+  for (; v < W; v++) {
+    const uint32_t e = word_end_slot[v];
+    if (e >= base) break;
+    const double s = sc[e];
+    if (s != kInf) mg.offer((s + wp) + t_b, am_b, bkp_new);
+  }
+  if (in_word) {
+    if (pos1) mg.offer(sc[p - 1] + t_fwd, am, bk[p - 1]);
+    if (has_loop) mg.offer(sc[p] + t_loop, am, bk[p]);
+  }
+  for (; v < W; v++) {
+    const double s = sc[word_end_slot[v]];
+    if (s != kInf) mg.offer((s + wp) + t_b, am_b, bkp_new);
+  }
+  return mg;
+}
+
+// REPLAY = false: the fast variant.  It carries no sequential-replay code; if an entry slot ever meets a
+// negative emission cost it raises out_flags bit 1 for the utterance and the whole workgroup stops.
+// REPLAY = true: launched right after on the same stream; workgroups of unflagged utterances exit at
+// once, flagged utterances are decoded again from frame 1 with the replay inline (exact, slower).
+template <int NT, int SPT, bool REPLAY>
+__global__ __launch_bounds__(NT) void decode_kernel(DecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t P = a.net.n_slots, W = a.net.n_words;
-  const uint32_t NT = blockDim.x, tid = threadIdx.x;
-  const uint32_t n_waves = NT >> 6, wave = tid >> 6, lane = tid & 63;
-  double* sc = reinterpret_cast<double*>(smem);                    // [P] hypothesis scores
-  double* red_best = sc + P;                                       // [16]
+  constexpr uint32_t kWavesPerWg = NT / 64;
+  const uint32_t P = a.net.n_slots;
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  constexpr uint32_t PP = NT * SPT;                                // slot arrays are padded to the thread grid
+  double* sc = reinterpret_cast<double*>(smem);                    // [PP] hypothesis scores
+  double* am_l = sc + PP;                                          // [PP] this frame's emission cost per slot (for position-1 slots' neighbours)
+  double* red_best = am_l + PP;                                    // [16]
   double* red_we = red_best + 16;                                  // [16]
   uint32_t* red_idx = reinterpret_cast<uint32_t*>(red_we + 16);    // [16]
   uint32_t* e_first = red_idx + 16;                                // [2][4] first word-end slot per class, by frame parity
-  uint16_t* bk = reinterpret_cast<uint16_t*>(e_first + 8);         // [P] back pointers (start frame of the word)
+  uint32_t* bail = e_first + 8;                                    // [1] fast variant: an entry slot needs the replay
+  uint16_t* bk = reinterpret_cast<uint16_t*>(e_first + 12);         // [PP] back pointers (start frame of the word)
 
   const uint32_t u = a.utt_first + blockIdx.x;
+  if (REPLAY && !(a.out_flags[u] & 2u)) return;  // wave-uniform: nothing to redo for this utterance
   const uint64_t f0 = a.frame_off[u];
   const uint32_t T = (uint32_t)(a.frame_off[u + 1] - f0);
   const double* row0 = a.scores + (f0 - a.frame_base) * a.ld;
@@ -84,134 +151,165 @@ __global__ __launch_bounds__(NTMAX) void decode_kernel(DecodeArgs a) {
   const double tl = a.net.tdp_loop, tf = a.net.tdp_forward, ts = a.net.tdp_skip;
   const double wp_word = a.word_penalty, thr = a.am_threshold;
 
-  // ---- static per-slot constants ---------------------------------------------------------------
-  uint32_t info[SPT], first_state[SPT];
+  // ---- static per-slot constants: info | first_state of the word (for position-1 slots) ------------
+  uint32_t info[SPT], pk[SPT];  // pk = bkp of the hypothesis being built
 #pragma unroll
   for (int i = 0; i < SPT; i++) {
     const uint32_t p = tid + i * NT;
     info[i] = p < P ? a.net.slot_info[p] : 0u;
-    // emission state of the word's position 0 (boundary candidates are scored with it even when
-    // they enter position 1, Recognizer.cpp:136,148-151)
-    first_state[i] = (info[i] & kSlotPos1) ? (a.net.slot_info[p - 1] & 0xFFFFu) : (info[i] & 0xFFFFu);
-    if (p < P) { sc[p] = kInf; bk[p] = 0; }
+    pk[i] = 0;
+    sc[p] = kInf; bk[p] = 0;
   }
   if (tid < 8) e_first[tid] = 0xFFFFFFFFu;
+  if (tid == 8) *bail = 0;
   __syncthreads();
   // initial hypothesis: word 0, position 0, score 0 (Recognizer.cpp:120)
-  double m_we = kInf;  // min over live word-end slots of the previous frame
-  if (a.net.slot_info[0] & kSlotEnd) m_we = 0.0;
+  const bool init_is_end = a.net.slot_info[0] & kSlotEnd;
+  double m_we = init_is_end ? 0.0 : kInf;  // min over live word-end slots of the previous frame
   if (tid == 0) {
     sc[0] = 0.0;
-    if (a.net.slot_info[0] & kSlotEnd) { e_first[0] = e_first[1] = e_first[2] = e_first[3] = 0; }  // parity of t=1 is 1 -> buffer 4..7
     a.tb_score[tb0] = 0.0; a.tb_word[tb0] = 0; a.tb_bkp[tb0] = 0;  // traceback[0] = Book(0.0,0,0,0), :118
   }
-  if (tid < 4 && (a.net.slot_info[0] & kSlotEnd)) e_first[4 + tid] = 0;
+  if (tid < 4 && init_is_end) e_first[4 + tid] = 0;  // frame t = 1 reads parity buffer 1
+  // Emission costs are gathered TWO frames ahead into two register sets (set f&1 holds frame f, frames are
+  // 1-based) and mirrored into am_l one frame ahead, so neither the frame body nor its barriers ever wait on
+  // HBM: the gathers of frame t+2 are issued at the top of frame t and first touched in phase C of frame t+1.
+  double am_s0[SPT], am_s1[SPT];
+#pragma unroll
+  for (int i = 0; i < SPT; i++) {
+    const uint32_t p = tid + i * NT;
+    am_s1[i] = T > 0 ? row0[info[i] & 0xFFFFu] : 0.0;  // padding slots carry state 0: a valid address, result unused
+    am_l[p] = am_s1[i];
+    am_s0[i] = T > 1 ? row0[a.ld + (info[i] & 0xFFFFu)] : 0.0;
+  }
   __syncthreads();
   uint32_t slow_taken = 0;
+#ifdef SR_DECODE_STAMPS
+  unsigned long long stamp_sum[6] = {0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
+#endif
 
-  for (uint32_t t = 1; t <= T; t++) {
-    const double* row = row0 + (uint64_t)(t - 1) * a.ld;
+  // one frame; returns true when the fast variant has to hand the utterance to the replay variant
+  auto frame = [&](const uint32_t t, double (&am_issue)[SPT], double (&am_consume)[SPT]) -> bool {
     const uint32_t* ef_cur = e_first + 4 * (t & 1);
     uint32_t* ef_nxt = e_first + 4 * ((t + 1) & 1);
     const uint32_t bkp_new = (t - 1) & 0xFFFFu;  // merge_hypothesis(.., t - 1, ..) truncated to uint16 (:154, Recognizer.hpp:79)
+    if (t + 2 <= T) {
+      const double* rown = row0 + (uint64_t)(t + 1) * a.ld;  // frame t+2
+#pragma unroll
+      for (int i = 0; i < SPT; i++) am_issue[i] = rown[info[i] & 0xFFFFu];
+    }
 
+    SR_STAMP(0);  // loop overhead + gather issue
     // ---- A: build the new hypotheses in registers ------------------------------------------------
+    // Branch-free: every slot makes the same five offers in ascending source order -- [boundary], skip,
+    // forward, loop, [boundary] -- where a candidate that does not exist for this slot is +inf, which
+    // Merge::offer ignores exactly like the reference ignores an absent hypothesis (:127-129).
     double nv[SPT];
-    uint32_t nb[SPT];
     double my_best = kInf, my_we = kInf;
     uint32_t my_we_idx = 0xFFFFFFFFu;
+    bool any_slow = false;
+#pragma unroll
+    for (int i = 0; i < SPT; i++) {
+      uint32_t p = tid + i * NT;
+      const bool live = p < P;
+      asm volatile("" : "+v"(p));  // keep p*8 / p*2 address math out of loop-invariant registers
+      // launder the slot constants: otherwise LICM hoists every derived per-slot value (tdp selects, word
+      // penalty, class: ~12 VGPRs per slot) out of the frame loop and occupancy drops to 1 wave/SIMD
+      uint32_t inf = info[i];
+      asm volatile("" : "+v"(inf));
+      const double am = am_l[p];
+      const bool pos0 = inf & kSlotPos0, pos1 = inf & kSlotPos1, entry = pos0 || pos1;
+      const bool sil_state = inf & kSlotSilState;
+      const double t_loop = sil_state ? tf : tl, t_fwd = tf, t_skip = sil_state ? tf : ts;
+      // unconditional LDS reads at clamped addresses; the selects below discard what does not apply
+      const uint32_t p1 = p - (pos0 ? 0u : 1u), p2 = p - (entry ? 0u : 2u);
+      const double s0 = sc[p], s1 = sc[p1], s2 = sc[p2], a1 = am_l[p1];
+      const uint32_t b_loop_ = bk[p], b_fwd_ = bk[p1], b_skip_ = bk[p2];
+      const double c_skip = entry ? kInf : s2 + t_skip;
+      const double c_fwd = pos0 ? kInf : s1 + t_fwd;
+      const double c_loop = (inf & kSlotEnd) ? kInf : s0 + t_loop;  // word ends do not expand in-word (:131)
+      // word-boundary candidate (positions 0 and 1 only)
+      const double am_b = pos1 ? a1 : am;  // emission of the word's position 0, even when entering position 1 (:136,148-151)
+      const double wp = (inf & kSlotSilWord) ? 0.0 : wp_word;
+      const bool b_skip = pos1 && !(inf & kSlotFirstSil);  // tdp(first_state, init + 1)
+      const double t_b = b_skip ? ts : tf;
+      const uint32_t cls = ((inf & kSlotSilWord) ? 0u : 2u) + (b_skip ? 1u : 0u);
+      const double c_b = entry ? (m_we + wp) + t_b : kInf;  // cur_hyp->score + word_penalty + tdp, :140
+      const uint32_t e_b = ef_cur[cls];                     // first word-end slot attaining c_b
+      const bool b_first = e_b < p1;                        // is that source visited before the in-word ones? (p1 == p for position 0)
+      Merge mg;
+      mg.offer(b_first ? c_b : kInf, am_b, bkp_new);
+      mg.offer(c_skip, am, b_skip_);
+      mg.offer(c_fwd, am, b_fwd_);
+      mg.offer(c_loop, am, b_loop_);
+      mg.offer(b_first ? kInf : c_b, am_b, bkp_new);
+      double extra = kInf;  // one-position word: boundary candidates with init = 1 land in a slot past the word's
+                            // end (Recognizer.cpp:139); it never expands but feeds best_score (:155)
+      if (live && (inf & kSlotSingle)) extra = ((m_we + wp) + ((inf & kSlotFirstSil) ? tf : ts)) + am;
+      // the collapsed boundary candidate is only exact while the pre-AM early-out (:143) is inert
+      const bool slow = live && (entry && (am_b < 0.0 || am < 0.0));
+      any_slow |= slow;
+      nv[i] = live ? mg.score : kInf; pk[i] = mg.bkp | (slow ? 0x80000000u : 0u);
+      const double lo = extra < nv[i] ? extra : nv[i];
+      my_best = lo < my_best ? lo : my_best;
+      // keep the slots' live ranges apart (otherwise every slot's LDS reads are hoisted to the top: +60 VGPRs)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!REPLAY) {
+      if (any_slow) *bail = 1;  // seen by everyone after the reduction barrier below
+    } else if (REPLAY && __any(any_slow)) {  // wave-uniform: some lane has a negative emission cost on an entry slot
+      slow_taken = 1;
+      my_best = kInf;
+#pragma unroll
+      for (int i = 0; i < SPT; i++) {
+        const uint32_t p = tid + i * NT;
+        const uint32_t inf = info[i];
+        if (pk[i] & 0x80000000u) {
+          const bool pos1 = inf & kSlotPos1;
+          const double am = am_l[p], am_b = pos1 ? am_l[p - 1] : am;
+          const double wp = (inf & kSlotSilWord) ? 0.0 : wp_word;
+          const bool sil_state = inf & kSlotSilState;
+          const double t_b = (pos1 && !(inf & kSlotFirstSil)) ? ts : tf;
+          const Merge mg = replay_boundary(a.net.word_end_slot, a.net.n_words, sc, bk, p, pos1, !(inf & kSlotEnd), true, wp, t_b, am_b, am, tf,
+                                           sil_state ? tf : tl, bkp_new);
+          nv[i] = mg.score; pk[i] = mg.bkp;
+        }
+        double extra = kInf;
+        if (p < P && (inf & kSlotSingle)) {
+          const double am = am_l[p];
+          const double wp = (inf & kSlotSilWord) ? 0.0 : wp_word;
+          const double t_d = (inf & kSlotFirstSil) ? tf : ts;
+          if (am >= 0.0) extra = ((m_we + wp) + t_d) + am;
+          else extra = replay_boundary(a.net.word_end_slot, a.net.n_words, sc, bk, p, false, false, false, wp, t_d, am, am, tf, tf, bkp_new).score;
+        }
+        const double lo = extra < nv[i] ? extra : nv[i];
+        my_best = lo < my_best ? lo : my_best;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < SPT; i++) {
       const uint32_t p = tid + i * NT;
-      nv[i] = kInf; nb[i] = 0;
-      if (p >= P) continue;
-      const uint32_t inf = info[i];
-      const double am = row[inf & 0xFFFFu];
-      const bool sil_state = inf & kSlotSilState;
-      const double t_loop = sil_state ? tf : tl, t_fwd = tf, t_skip = sil_state ? tf : ts;
-      Merge mg;
-      if (!(inf & (kSlotPos0 | kSlotPos1))) {
-        // position >= 2: skip from p-2, forward from p-1, loop from p (not for a word end)
-        mg.offer(sc[p - 2] + t_skip, am, bk[p - 2]);
-        mg.offer(sc[p - 1] + t_fwd, am, bk[p - 1]);
-        if (!(inf & kSlotEnd)) mg.offer(sc[p] + t_loop, am, bk[p]);
-      } else {
-        const bool pos1 = inf & kSlotPos1;
-        const double am_b = pos1 ? row[first_state[i]] : am;
-        const double wp = (inf & kSlotSilWord) ? 0.0 : wp_word;
-        // tdp(first_state, init + 1): init 0 -> forward; init 1 -> skip unless the first state is silence
-        const bool b_skip = pos1 && !(inf & kSlotFirstSil);
-        const double t_b = b_skip ? ts : tf;
-        const uint32_t cls = ((inf & kSlotSilWord) ? 0u : 2u) + (b_skip ? 1u : 0u);
-        if (am_b >= 0.0 && am >= 0.0) {
-          const double c_b = (m_we + wp) + t_b;   // cur_hyp->score + word_penalty + tdp, :140
-          const uint32_t e_b = ef_cur[cls];       // first word-end slot attaining c_b
-          if (!pos1) {
-            if (e_b < p) mg.offer(c_b, am_b, bkp_new);
-            if (!(inf & kSlotEnd)) mg.offer(sc[p] + t_loop, am, bk[p]);
-            if (e_b >= p) mg.offer(c_b, am_b, bkp_new);
-          } else {
-            if (e_b < p - 1) mg.offer(c_b, am_b, bkp_new);
-            mg.offer(sc[p - 1] + t_fwd, am, bk[p - 1]);
-            if (!(inf & kSlotEnd)) mg.offer(sc[p] + t_loop, am, bk[p]);
-            if (e_b >= p - 1) mg.offer(c_b, am_b, bkp_new);
-          }
-        } else {
-          // negative emission cost: replay the boundary loop source by source in slot order
-          slow_taken = 1;
-          const uint32_t base = pos1 ? p - 1 : p;  // slot of position 0 of this word
-          uint32_t v = 0;
-          for (; v < W; v++) {
-            const uint32_t e = a.net.word_end_slot[v];
-            if (e >= base) break;
-            const double s = sc[e];
-            if (s != kInf) mg.offer((s + wp) + t_b, am_b, bkp_new);
-          }
-          if (pos1) mg.offer(sc[p - 1] + t_fwd, am, bk[p - 1]);
-          if (!(inf & kSlotEnd)) mg.offer(sc[p] + t_loop, am, bk[p]);
-          for (; v < W; v++) {
-            const double s = sc[a.net.word_end_slot[v]];
-            if (s != kInf) mg.offer((s + wp) + t_b, am_b, bkp_new);
-          }
-        }
-        if (inf & kSlotSingle) {
-          // one-position word: boundary candidates with init = 1 land in a slot past the word's
-          // end (Recognizer.cpp:139); it never expands but feeds best_score (:155).
-          const bool d_skip = !(inf & kSlotFirstSil);
-          const double t_d = d_skip ? ts : tf;
-          Merge dead;
-          if (am >= 0.0) {
-            dead.offer((m_we + wp) + t_d, am, bkp_new);
-          } else {
-            slow_taken = 1;
-            for (uint32_t v = 0; v < W; v++) {
-              const double s = sc[a.net.word_end_slot[v]];
-              if (s != kInf) dead.offer((s + wp) + t_d, am, bkp_new);
-            }
-          }
-          my_best = dead.score < my_best ? dead.score : my_best;
-        }
-      }
-      nv[i] = mg.score; nb[i] = mg.bkp;
-      my_best = mg.score < my_best ? mg.score : my_best;
-      if ((inf & kSlotEnd) && (mg.score < my_we || (mg.score == my_we && p < my_we_idx))) { my_we = mg.score; my_we_idx = p; }
+      pk[i] &= 0xFFFFu;
+      if (p < P && (info[i] & kSlotEnd) && (nv[i] < my_we || (nv[i] == my_we && p < my_we_idx))) { my_we = nv[i]; my_we_idx = p; }
     }
     if (tid < 4) ef_nxt[tid] = 0xFFFFFFFFu;
 
+    SR_STAMP(1);  // phase A
     // ---- B: block reductions -----------------------------------------------------------------------
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-      const double ob = shfl_xor_f64(my_best, m);
-      my_best = ob < my_best ? ob : my_best;
-      const double ow = shfl_xor_f64(my_we, m);
-      const uint32_t oi = __shfl_xor(my_we_idx, m);
-      if (ow < my_we || (ow == my_we && oi < my_we_idx)) { my_we = ow; my_we_idx = oi; }
-    }
+    my_best = wave_min(my_best);
+    wave_min_idx(my_we, my_we_idx);
     if (lane == 0) { red_best[wave] = my_best; red_we[wave] = my_we; red_idx[wave] = my_we_idx; }
+    SR_STAMP(2);  // wave reductions
     __syncthreads();  // also: every read of sc/bk of frame t-1 is done
+    SR_STAMP(3);  // barrier 1
+    if (!REPLAY && *bail) {  // workgroup-uniform
+      if (tid == 0) { atomicOr(&a.out_flags[u], 2u); a.out_count[u] = 0; }
+      return true;
+    }
     double best = red_best[0], we = red_we[0];
     uint32_t we_idx = red_idx[0];
-    for (uint32_t w = 1; w < n_waves; w++) {
+#pragma unroll
+    for (uint32_t w = 1; w < kWavesPerWg; w++) {
       const double ob = red_best[w];
       best = ob < best ? ob : best;
       const double ow = red_we[w];
@@ -223,30 +321,48 @@ __global__ __launch_bounds__(NTMAX) void decode_kernel(DecodeArgs a) {
     const double limit = best + thr;
     const bool we_alive = !(we > limit) && we != kInf;
     m_we = we_alive ? we : kInf;
+    // a word end other than we_idx can only tie the boundary candidate of the minimum if it rounds to
+    // the same sum: its score is within a few ulps of the minimum (cheap, safe pre-filter)
+    const double near = m_we + (fabs(m_we) + fabs(wp_word) + fabs(tf) + fabs(ts) + 1.0) * 1e-9;
 #pragma unroll
     for (int i = 0; i < SPT; i++) {
       const uint32_t p = tid + i * NT;
-      if (p >= P) continue;
       double v = nv[i];
       if (v > limit) v = kInf;  // :194-196
       sc[p] = v;
-      bk[p] = (uint16_t)nb[i];
-      if ((info[i] & kSlotEnd) && v != kInf && we_alive) {
+      bk[p] = (uint16_t)pk[i];
+      am_l[p] = am_consume[i];  // next frame's emission costs (gathered two frames ago)
+      if ((info[i] & kSlotEnd) && we_alive && v <= near) {
         if (p == we_idx) {  // first minimal surviving word end -> traceback[t] (:199-205)
-          a.tb_score[tb0 + t] = v; a.tb_word[tb0 + t] = (uint16_t)(a.net.slot_word[p]); a.tb_bkp[tb0 + t] = (uint16_t)nb[i];
+          a.tb_score[tb0 + t] = v; a.tb_word[tb0 + t] = (uint16_t)p; a.tb_bkp[tb0 + t] = (uint16_t)pk[i];  // slot now, word after the loop
         }
-        // first slot (in index order) whose boundary candidate equals the minimum, per class
+        // first slot (in index order) whose boundary candidate equals the minimum's, per (wp, tdp) class
         if (v + 0.0 + tf == m_we + 0.0 + tf) atomicMin(&ef_nxt[0], p);
         if (v + 0.0 + ts == m_we + 0.0 + ts) atomicMin(&ef_nxt[1], p);
         if (v + wp_word + tf == m_we + wp_word + tf) atomicMin(&ef_nxt[2], p);
         if (v + wp_word + ts == m_we + wp_word + ts) atomicMin(&ef_nxt[3], p);
       }
     }
-    if (!we_alive && tid == 0) { a.tb_score[tb0 + t] = kInf; a.tb_word[tb0 + t] = 0; a.tb_bkp[tb0 + t] = 0; }
+    if (!we_alive && tid == 0) { a.tb_score[tb0 + t] = kInf; a.tb_word[tb0 + t] = 0xFFFFu; a.tb_bkp[tb0 + t] = 0; }
+    SR_STAMP(4);  // partial combine + phase C
     __syncthreads();
+    SR_STAMP(5);  // barrier 2
+    return false;
+  };
+
+  for (uint32_t t = 1; t <= T; t += 2) {
+    if (frame(t, am_s1, am_s0)) return;                 // odd frame: refill set 1 (frame t+2), mirror set 0 (frame t+1)
+    if (t + 1 <= T && frame(t + 1, am_s0, am_s1)) return;
   }
 
   // ---- traceback (Recognizer.cpp:222-231) -------------------------------------------------------------
+  __threadfence();
+  __syncthreads();
+  // entries 1..T hold the winning word-end SLOT (0xFFFF: no surviving word end -> word 0, :118,191): map to words
+  for (uint32_t t = 1 + tid; t <= T; t += NT) {
+    const uint32_t sl = __hip_atomic_load(&a.tb_word[tb0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a.tb_word[tb0 + t] = sl == 0xFFFFu ? (uint16_t)0 : (uint16_t)a.net.slot_word[sl];
+  }
   __threadfence();
   __syncthreads();
   if (slow_taken) atomicOr(&a.out_flags[u], 1u);
@@ -261,29 +377,42 @@ __global__ __launch_bounds__(NTMAX) void decode_kernel(DecodeArgs a) {
     for (uint32_t i = 0; i < n / 2; i++) { const uint32_t x = words[i]; words[i] = words[n - 1 - i]; words[n - 1 - i] = x; }
     a.out_count[u] = n;
   }
+#ifdef SR_DECODE_STAMPS
+  if (tid == 0)
+    for (int k = 0; k < 6 && k + 1 <= (int)T; k++) a.tb_score[tb0 + 1 + k] = (double)stamp_sum[k];
+#endif
 }
 
 uint32_t decode_max_slots() { return 8192; }
 
-static size_t decode_smem(uint32_t P) { return (size_t)P * 8 + 16 * 8 * 2 + 16 * 4 + 8 * 4 + (size_t)P * 2 + 16; }
+static size_t decode_smem(uint32_t PP) { return (size_t)PP * 16 + 16 * 8 * 2 + 16 * 4 + 12 * 4 + (size_t)PP * 2 + 16; }
 
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream) {
   if (a.n_utts == 0) return hipSuccess;
   const uint32_t P = a.net.n_slots;
-  const size_t smem = decode_smem(P);
   const dim3 grid(a.n_utts);
-#define SR_LAUNCH(SPT, NT)                                                                                   \
+#define SR_LAUNCH(NT, SPT)                                                                                   \
   do {                                                                                                       \
-    hipError_t e = hipFuncSetAttribute((const void*)decode_kernel<SPT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    const size_t smem = decode_smem((NT) * (SPT));                                                           \
+    hipError_t e = hipFuncSetAttribute((const void*)decode_kernel<NT, SPT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)decode_kernel<NT, SPT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
     if (e != hipSuccess) return e;                                                                           \
-    hipLaunchKernelGGL((decode_kernel<SPT, NT>), grid, dim3(NT), smem, stream, a);                               \
+    hipLaunchKernelGGL((decode_kernel<NT, SPT, false>), grid, dim3(NT), smem, stream, a);                    \
+    if ((e = hipGetLastError()) != hipSuccess) return e;                                                     \
+    hipLaunchKernelGGL((decode_kernel<NT, SPT, true>), grid, dim3(NT), smem, stream, a);                     \
     return hipGetLastError();                                                                                \
   } while (0)
-  if (P <= 64) SR_LAUNCH(1, 64);
-  if (P <= 256) SR_LAUNCH(1, 256);
-  if (P <= 1024) SR_LAUNCH(4, 256);
-  if (P <= 4096) SR_LAUNCH(4, 1024);
-  if (P <= 8192) SR_LAUNCH(8, 1024);
+  // tuning override: SRGPU_DECODE_GEOM = threads*100 + slots_per_thread (e.g. 102404)
+  static const int geom = getenv("SRGPU_DECODE_GEOM") ? atoi(getenv("SRGPU_DECODE_GEOM")) : 0;
+  if (geom == 102404 && P <= 4096) SR_LAUNCH(1024, 4);
+  if (geom == 51208 && P <= 4096) SR_LAUNCH(512, 8);
+  if (geom == 25616 && P <= 4096) SR_LAUNCH(256, 16);
+  if (P <= 64) SR_LAUNCH(64, 1);
+  if (P <= 256) SR_LAUNCH(64, 4);
+  if (P <= 1024) SR_LAUNCH(256, 4);
+  if (P <= 2048) SR_LAUNCH(256, 8);
+  if (P <= 4096) SR_LAUNCH(512, 8);
+  if (P <= 8192) SR_LAUNCH(1024, 8);
 #undef SR_LAUNCH
   return hipErrorInvalidValue;
 }
