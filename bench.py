@@ -102,15 +102,10 @@ def main():
     prof = model.profile_read()
     model.profile(False)
 
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        fr = torch.tensor([n_frames], dtype=torch.float64, device="cuda")
-        dist.all_reduce(fr, op=dist.ReduceOp.SUM)
-        total_frames = float(fr.item())
-    else:
-        total_frames = float(n_frames)
+    from speechrecognition_amd import sharding
+
+    elapsed, total_frames = sharding.reduce_timing(elapsed, n_frames, dist if distributed else None,
+                                                   torch.device("cuda", local_rank))
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3

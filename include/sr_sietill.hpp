@@ -1,0 +1,355 @@
+// sr_sietill.hpp -- C++ host-side mirror of the reference's scorer / search interface, on top of the
+// C ABI in srgpu.h.  Header-only; link with libsrgpu.so.
+//
+// Same names, argument meaning and error behaviour as the reference classes for this path, so code
+// (and tests) written against `sietill` read the same:
+//
+//   sr::FeatureScorer          FeatureScorer                sietill/FeatureScorer.hpp:12-16
+//   sr::Lexicon                Lexicon / MarkovAutomaton    sietill/Lexicon.hpp:16-33, MarkovAutomaton.hpp:17-67
+//   sr::TdpModel               TdpModel                     sietill/TdpModel.hpp:13-29, TdpModel.cpp:19-29
+//   sr::MixtureModel           MixtureModel (as scorer)     sietill/Mixtures.hpp:18-92
+//   sr::Corpus                 Corpus (feature store)       sietill/Corpus.hpp:55-84
+//   sr::Recognizer             Recognizer                   sietill/Recognizer.hpp:91-132
+//   sr::Aligner                Aligner                      sietill/Alignment.hpp:19-63
+//
+// Differences, all forced by the device boundary: features are passed as (pointer, frame count)
+// instead of FeatureIter pairs; MixtureModel::prepare_sequence really does work (it fills the dense
+// score table on the GPU, like NeuralNetwork::prepare_sequence does on the CPU,
+// sietill/NeuralNetwork.cpp:184-199); errors that the reference reports with abort()
+// (Mixtures.cpp:97-102) are thrown as std::runtime_error carrying the same text.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <limits>
+#include <stdexcept>
+#include <time.h>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "srgpu.h"
+
+namespace sr {
+
+typedef size_t WordIdx;     // sietill/Types.hpp:14-17
+typedef uint16_t StateIdx;
+
+inline void check(int rc) {
+  if (rc != SR_OK) throw std::runtime_error(sr_last_error());
+}
+
+// ---- FeatureScorer.hpp:12-16 ----------------------------------------------------------------------
+class FeatureScorer {
+ public:
+  virtual ~FeatureScorer() {}
+  virtual void prepare_sequence(const float* begin, size_t n_frames) = 0;
+  virtual double score(size_t frame, StateIdx state_idx) const = 0;
+};
+
+// ---- MarkovAutomaton.hpp:17-67, Lexicon.cpp:11-62 ---------------------------------------------------
+struct MarkovAutomaton {
+  std::vector<StateIdx> states;
+  MarkovAutomaton() {}
+  MarkovAutomaton(StateIdx start, uint16_t num, uint16_t repetitions) {
+    for (StateIdx s = start; s < start + num; s++) states.insert(states.end(), repetitions, s);
+  }
+  StateIdx first_state() const { return states.front(); }
+  StateIdx last_state() const { return states.back(); }
+  size_t num_states() const { return states.size(); }
+  StateIdx operator[](size_t i) const { return states[i]; }
+  static MarkovAutomaton concat(std::vector<MarkovAutomaton const*> automata) {
+    MarkovAutomaton r;
+    for (auto a : automata) r.states.insert(r.states.end(), a->states.begin(), a->states.end());
+    return r;
+  }
+};
+
+class Lexicon {
+ public:
+  WordIdx add_word(std::string const& orth, uint16_t num_states, uint16_t state_repetitions, bool silence = false) {
+    const WordIdx w = automata_.size();
+    if (silence) silence_ = w;
+    const StateIdx start = automata_.empty() ? 0 : StateIdx(automata_.back().last_state() + 1);
+    orth_.push_back(orth);
+    automata_.push_back(MarkovAutomaton(start, num_states, state_repetitions));
+    return w;
+  }
+  MarkovAutomaton const& get_silence_automaton() const { return automata_[silence_]; }
+  MarkovAutomaton const& get_automaton_for_word(WordIdx w) const { return automata_[w]; }
+  StateIdx num_states() const { return automata_.back().last_state() + 1; }
+  WordIdx num_words() const { return automata_.size(); }
+  WordIdx silence_idx() const { return silence_; }
+  WordIdx operator[](std::string const& orth) const {
+    auto it = std::find(orth_.begin(), orth_.end(), orth);
+    return it == orth_.end() ? WordIdx(-1) : WordIdx(it - orth_.begin());  // Lexicon.cpp:57-62
+  }
+
+ private:
+  std::vector<std::string> orth_;
+  std::vector<MarkovAutomaton> automata_;
+  WordIdx silence_ = 0;
+};
+
+// ---- TdpModel.cpp:19-29 ------------------------------------------------------------------------------
+struct TdpModel {
+  StateIdx silence_state;
+  double tdp_loop, tdp_forward, tdp_skip;
+  TdpModel(StateIdx silence_state, double loop, double forward, double skip)
+      : silence_state(silence_state), tdp_loop(loop), tdp_forward(forward), tdp_skip(skip) {}
+  double score(StateIdx to, size_t jump) const {
+    if (to == silence_state) return tdp_forward;
+    switch (jump) {
+      case 0: return tdp_loop;
+      case 1: return tdp_forward;
+      case 2: return tdp_skip;
+    }
+    return std::numeric_limits<double>::infinity();
+  }
+};
+
+// ---- Mixtures.hpp:18-92: the GMM as a FeatureScorer, resident on one GPU ----------------------------------
+class MixtureModel : public FeatureScorer {
+ public:
+  enum VarianceModel { GLOBAL_POOLING, MIXTURE_POOLING, NO_POOLING };  // Mixtures.hpp:20-24
+
+  // MixtureModel(config, dimension, num_mixtures, var_model, max_approx) with action "recognize" and
+  // "load-mixtures-from" = path (Mixtures.cpp:156-174)
+  MixtureModel(std::string const& load_mixtures_from, size_t dimension, VarianceModel var_model, bool max_approx,
+               int device = 0, int gmm_kernel = SR_GMM_MFMA)
+      : dimension(dimension), var_model(var_model), gmm_kernel(gmm_kernel) {
+    check(sr_model_load_mixset(load_mixtures_from.c_str(), (uint32_t)dimension, (int)var_model, max_approx ? 1 : 0, device, &h_));
+    uint32_t d, s;
+    uint64_t c;
+    check(sr_model_info(h_, &d, &s, &c));
+    num_mixtures_ = s;
+    num_densities_ = c;
+  }
+  ~MixtureModel() { sr_model_destroy(h_); }
+  MixtureModel(MixtureModel const&) = delete;
+  MixtureModel& operator=(MixtureModel const&) = delete;
+
+  const size_t dimension;
+  const VarianceModel var_model;
+  int gmm_kernel;
+
+  size_t num_mixtures() const { return num_mixtures_; }
+  size_t num_densities() const { return num_densities_; }
+  sr_model* handle() const { return h_; }
+
+  // FeatureScorer: one dense [T x S] table per sequence
+  void prepare_sequence(const float* begin, size_t n_frames) override {
+    table_.resize(n_frames * num_mixtures_);
+    check(sr_score_frames(h_, begin, n_frames, gmm_kernel, table_.data()));
+  }
+  double score(size_t frame, StateIdx mixture_idx) const override { return table_[frame * num_mixtures_ + mixture_idx]; }
+
+ private:
+  sr_model* h_ = nullptr;
+  size_t num_mixtures_ = 0, num_densities_ = 0;
+  std::vector<double> table_;
+};
+
+// ---- Corpus.hpp:55-84: contiguous features + offsets + reference word sequences ---------------------------
+class Corpus {
+ public:
+  explicit Corpus(size_t features_per_timeframe, double frame_duration = 0.010)
+      : features_per_timeframe_(features_per_timeframe), frame_duration_(frame_duration) {
+    frame_offsets_.push_back(0);
+    orth_offsets_.push_back(0);
+  }
+  void add_segment(const float* feats, size_t n_frames, std::vector<WordIdx> const& orth) {
+    features_.insert(features_.end(), feats, feats + n_frames * features_per_timeframe_);
+    frame_offsets_.push_back(frame_offsets_.back() + n_frames);
+    orths_.insert(orths_.end(), orth.begin(), orth.end());
+    orth_offsets_.push_back(orths_.size());
+  }
+  size_t get_corpus_size() const { return orth_offsets_.size() - 1; }
+  size_t get_total_frame_count() const { return frame_offsets_.back(); }
+  size_t get_features_per_timeframe() const { return features_per_timeframe_; }
+  double get_frame_duration() const { return frame_duration_; }
+  std::pair<const WordIdx*, const WordIdx*> get_word_sequence(size_t s) const {
+    return {orths_.data() + orth_offsets_[s], orths_.data() + orth_offsets_[s + 1]};
+  }
+  std::pair<const float*, size_t> get_feature_sequence(size_t s) const {
+    return {features_.data() + frame_offsets_[s] * features_per_timeframe_, (size_t)(frame_offsets_[s + 1] - frame_offsets_[s])};
+  }
+  const float* features() const { return features_.data(); }
+  const uint64_t* frame_offsets() const { return frame_offsets_.data(); }
+
+ private:
+  size_t features_per_timeframe_;
+  double frame_duration_;
+  std::vector<uint64_t> frame_offsets_;
+  std::vector<float> features_;
+  std::vector<size_t> orth_offsets_;
+  std::vector<WordIdx> orths_;
+};
+
+// ---- Recognizer.hpp:18-47 ---------------------------------------------------------------------------------
+struct EDAccumulator {
+  uint16_t total_count = 0, substitute_count = 0, insert_count = 0, delete_count = 0;
+  EDAccumulator& operator+=(EDAccumulator const& o) {
+    total_count += o.total_count; substitute_count += o.substitute_count;
+    insert_count += o.insert_count; delete_count += o.delete_count;
+    return *this;
+  }
+  void substitution_error() { total_count++; substitute_count++; }
+  void insertion_error() { total_count++; insert_count++; }
+  void deletion_error() { total_count++; delete_count++; }
+};
+
+struct RecognitionStats {  // what Recognizer::recognize prints (Recognizer.cpp:82-91)
+  EDAccumulator errors;
+  size_t ref_words = 0, sentence_errors = 0, corpus_size = 0;
+  double wer = 0, ser = 0, seconds = 0, rtf = 0;
+  std::vector<std::vector<WordIdx>> hypotheses;
+};
+
+class Recognizer {
+ public:
+  // Recognizer(config, lexicon, scorer, tdp_model): "am-threshold" (20.0), "word-penalty" (10.0),
+  // "max-recognition-runs" (1000) as in Recognizer.cpp:31-34
+  Recognizer(Lexicon const& lexicon, MixtureModel& scorer, TdpModel const& tdp_model, double am_threshold = 20.0,
+             double word_penalty = 10.0, size_t max_recognition_runs = 1000)
+      : am_threshold_(am_threshold), word_penalty_(word_penalty), max_recognition_runs_(max_recognition_runs),
+        lexicon_(lexicon), scorer_(scorer) {
+    std::vector<uint32_t> word_off(1, 0);
+    std::vector<uint16_t> automaton;
+    for (WordIdx w = 0; w < lexicon.num_words(); w++) {
+      auto const& a = lexicon.get_automaton_for_word(w);
+      automaton.insert(automaton.end(), a.states.begin(), a.states.end());
+      word_off.push_back((uint32_t)automaton.size());
+    }
+    const double tdp[3] = {tdp_model.tdp_loop, tdp_model.tdp_forward, tdp_model.tdp_skip};
+    check(sr_lexicon_create(scorer.handle(), (uint32_t)lexicon.num_words(), word_off.data(), automaton.data(),
+                            (uint32_t)lexicon.silence_idx(), tdp, tdp_model.silence_state, &net_));
+  }
+  ~Recognizer() { sr_lexicon_destroy(net_); }
+  Recognizer(Recognizer const&) = delete;
+
+  // Recognizer::recognizeSequence_pruned (Recognizer.cpp:103-232)
+  void recognizeSequence_pruned(const float* feature_begin, size_t n_frames, std::vector<WordIdx>& output) {
+    const uint64_t off[2] = {0, n_frames};
+    std::vector<uint32_t> words(std::max<size_t>(n_frames, 1));
+    uint64_t woff[2];
+    const sr_search_params p = {am_threshold_, word_penalty_, scorer_.gmm_kernel, 0};
+    check(sr_recognize_batch(scorer_.handle(), net_, &p, feature_begin, off, 1, words.data(), woff));
+    output.assign(words.begin(), words.begin() + woff[1]);
+  }
+
+  // Recognizer::recognize (Recognizer.cpp:38-92): the whole corpus in one device pass
+  RecognitionStats recognize(Corpus const& corpus) {
+    RecognitionStats st;
+    const size_t n = std::min(corpus.get_corpus_size(), max_recognition_runs_);
+    st.corpus_size = n;
+    const uint64_t total = corpus.frame_offsets()[n];
+    std::vector<uint32_t> words(std::max<uint64_t>(total, 1));
+    std::vector<uint64_t> woff(n + 1);
+    const sr_search_params p = {am_threshold_, word_penalty_, scorer_.gmm_kernel, 0};
+    const double t0 = now();
+    check(sr_recognize_batch(scorer_.handle(), net_, &p, corpus.features(), corpus.frame_offsets(), (uint32_t)n,
+                             words.data(), woff.data()));
+    st.seconds = now() - t0;
+    for (size_t s = 0; s < n; s++) {
+      std::vector<WordIdx> hyp(words.begin() + woff[s], words.begin() + woff[s + 1]);
+      auto ref = corpus.get_word_sequence(s);
+      EDAccumulator ed = editDistance(ref.first, ref.second, hyp.data(), hyp.data() + hyp.size());
+      st.errors += ed;
+      st.ref_words += ref.second - ref.first;
+      if (ed.total_count > 0) st.sentence_errors++;
+      st.hypotheses.push_back(std::move(hyp));
+    }
+    st.wer = 100.0 * st.errors.total_count / (double)st.ref_words;
+    st.ser = 100.0 * st.sentence_errors / (double)n;
+    st.rtf = st.seconds / (corpus.get_frame_duration() * (double)total);  // Recognizer.cpp:85
+    return st;
+  }
+
+  // Recognizer::editDistance (Recognizer.cpp:332-389), including its 16-bit counters and the stale row-0
+  // insertion counter (`current_rates[0].insertion_error()` after the swap, :349-352)
+  static EDAccumulator editDistance(const WordIdx* ref_begin, const WordIdx* ref_end, const WordIdx* rec_begin,
+                                    const WordIdx* rec_end) {
+    const size_t ref_size = ref_end - ref_begin, hyp_size = rec_end - rec_begin;
+    std::vector<EDAccumulator> current(1 + ref_size), previous(1 + ref_size);
+    for (size_t r = 1; r <= ref_size; r++) { current[r] = current[r - 1]; current[r].deletion_error(); }
+    for (size_t h = 1; h <= hyp_size; h++) {
+      current.swap(previous);
+      current[0].insertion_error();
+      for (size_t r = 1; r <= ref_size; r++) {
+        uint16_t best = 0xFFFF;
+        if (previous[r - 1].total_count < best && ref_begin[r - 1] == rec_begin[h - 1]) {
+          current[r] = previous[r - 1]; best = current[r].total_count;
+        }
+        if (previous[r - 1].total_count + 1 < best) {
+          current[r] = previous[r - 1]; current[r].substitution_error(); best = current[r].total_count;
+        }
+        if (previous[r].total_count + 1 < best) {
+          current[r] = previous[r]; current[r].insertion_error(); best = current[r].total_count;
+        }
+        if (current[r - 1].total_count + 1 < best) {
+          current[r] = current[r - 1]; current[r].deletion_error(); best = current[r].total_count;
+        }
+      }
+    }
+    return current[ref_size];
+  }
+
+ private:
+  static double now() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);  // Timer.hpp:11-40
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+  }
+  const double am_threshold_, word_penalty_;
+  const size_t max_recognition_runs_;
+  Lexicon const& lexicon_;
+  MixtureModel& scorer_;
+  sr_lexicon* net_ = nullptr;
+};
+
+// ---- Alignment.hpp:19-63 -------------------------------------------------------------------------------------
+struct AlignmentItem {  // sietill/Types.hpp:29-38
+  uint16_t count = 0;
+  StateIdx state = 0;
+  float weight = 0.0f;
+};
+
+class Aligner {
+ public:
+  Aligner(MixtureModel& mixtures, TdpModel const& tdp_model) : mixtures_(mixtures), tdp_(tdp_model) {}
+
+  // Aligner::align_sequence_full (Alignment.cpp:50-144); alignment receives one item per frame
+  double align_sequence_full(const float* feature_begin, size_t n_frames, MarkovAutomaton const& reference,
+                             std::vector<AlignmentItem>& alignment) {
+    return run(feature_begin, n_frames, reference, alignment, false, 0.0);
+  }
+  // Aligner::align_sequence_pruned (Alignment.cpp:149-288)
+  double align_sequence_pruned(const float* feature_begin, size_t n_frames, MarkovAutomaton const& reference,
+                               std::vector<AlignmentItem>& alignment, double pruning_threshold) {
+    return run(feature_begin, n_frames, reference, alignment, true, pruning_threshold);
+  }
+
+ private:
+  double run(const float* feats, size_t T, MarkovAutomaton const& ref, std::vector<AlignmentItem>& alignment, bool pruned,
+             double thr) {
+    const uint64_t foff[2] = {0, T}, aoff[2] = {0, ref.num_states()};
+    const double tdp[3] = {tdp_.tdp_loop, tdp_.tdp_forward, tdp_.tdp_skip};
+    sr_corpus* c = nullptr;
+    check(sr_corpus_upload(mixtures_.handle(), feats, foff, 1, &c));
+    std::vector<uint16_t> states(std::max<size_t>(T, 1));
+    double cost = 0.0;
+    const int rc = pruned ? sr_align_corpus_pruned(mixtures_.handle(), c, ref.states.data(), aoff, tdp, tdp_.silence_state, thr,
+                                                   mixtures_.gmm_kernel, states.data(), &cost)
+                          : sr_align_corpus(mixtures_.handle(), c, ref.states.data(), aoff, tdp, tdp_.silence_state,
+                                            mixtures_.gmm_kernel, states.data(), &cost);
+    sr_corpus_destroy(c);
+    check(rc);
+    alignment.assign(T, AlignmentItem());
+    for (size_t t = 0; t < T; t++) { alignment[t].state = states[t]; alignment[t].weight = 1; alignment[t].count = 1; }
+    return cost;
+  }
+  MixtureModel& mixtures_;
+  TdpModel tdp_;
+};
+
+}  // namespace sr

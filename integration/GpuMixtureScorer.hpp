@@ -1,0 +1,104 @@
+// GpuMixtureScorer.hpp -- the binding a maintainer of kkromberg/SpeechRecognition would drop into
+// src/sietill/ to put libsrgpu.so behind the reference's own FeatureScorer / Recognizer interfaces.
+// It is written against the REFERENCE's headers (FeatureScorer.hpp, Iter.hpp, Lexicon.hpp, TdpModel.hpp,
+// Corpus.hpp), so it only compiles inside that tree: tests/test_integration_stub.py syntax-checks it
+// against /root/reference when that is present.  Nothing in this repo's product path includes it.
+//
+//   GpuMixtureScorer : FeatureScorer     plug-in for `"feature-scorer": "gmm-gpu"` in SieTill.cpp:116-131;
+//                                        per-sequence dense table like NeuralNetwork (NeuralNetwork.cpp:184-199)
+//   gpu_recognize(...)                   batch replacement for the utterance loop of Recognizer::recognize
+//                                        (Recognizer.cpp:46-78): one device pass over the whole Corpus
+#ifndef __GPU_MIXTURE_SCORER_HPP__
+#define __GPU_MIXTURE_SCORER_HPP__
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "Corpus.hpp"
+#include "FeatureScorer.hpp"
+#include "Lexicon.hpp"
+#include "TdpModel.hpp"
+#include "srgpu.h"
+
+class GpuMixtureScorer : public FeatureScorer {
+public:
+  // same arguments as MixtureModel's constructor in recognize mode (Mixtures.cpp:156-174); pooling is
+  // MixtureModel::VarianceModel cast to int
+  GpuMixtureScorer(std::string const& mixture_path, size_t dimension, int pooling, bool max_approx, int device = 0)
+                  : dimension_(dimension), model_(NULL), start_(NULL) {
+    if (sr_model_load_mixset(mixture_path.c_str(), dimension, pooling, max_approx, device, &model_) != SR_OK) {
+      throw std::runtime_error(sr_last_error());
+    }
+    uint32_t d; uint64_t c;
+    sr_model_info(model_, &d, &num_states_, &c);
+  }
+  virtual ~GpuMixtureScorer() { sr_model_destroy(model_); }
+
+  // NOTE: like NeuralNetwork::prepare_sequence this keeps per-sequence state, so it is not safe under the
+  // `#pragma omp parallel for` of Recognizer::recognize (Recognizer.cpp:46); use gpu_recognize() for corpora.
+  virtual void prepare_sequence(FeatureIter const& start, FeatureIter const& end) {
+    const size_t n_frames = end - start;
+    start_ = *start;
+    table_.resize(n_frames * num_states_);
+    if (sr_score_frames(model_, *start, n_frames, SR_GMM_MFMA, table_.data()) != SR_OK) {
+      throw std::runtime_error(sr_last_error());
+    }
+  }
+
+  virtual double score(FeatureIter const& iter, StateIdx state_idx) const {
+    const size_t frame = (*iter - start_) / dimension_;  // as NeuralNetwork::score recovers it (NeuralNetwork.cpp:196-198)
+    return table_[frame * num_states_ + state_idx];
+  }
+
+  sr_model* handle() const { return model_; }
+
+private:
+  size_t              dimension_;
+  sr_model*           model_;
+  uint32_t            num_states_;
+  const float*        start_;
+  std::vector<double> table_;
+};
+
+// Whole-corpus recognition on the device: what Recognizer::recognize's loop body computes per segment
+// (Recognizer.cpp:48-56), for every segment at once.  Fills `recognized` with one word sequence per segment.
+inline void gpu_recognize(GpuMixtureScorer const& scorer, Lexicon const& lexicon, TdpModel const& tdp_model,
+                          double tdp_loop, double tdp_forward, double tdp_skip,
+                          double am_threshold, double word_penalty, Corpus const& corpus, size_t corpus_size,
+                          std::vector<std::vector<WordIdx> >& recognized) {
+  std::vector<uint32_t> word_off(1, 0u);
+  std::vector<uint16_t> automaton;
+  for (WordIdx w = 0; w < lexicon.num_words(); w++) {
+    MarkovAutomaton const& a = lexicon.get_automaton_for_word(w);
+    automaton.insert(automaton.end(), a.states.begin(), a.states.end());
+    word_off.push_back(automaton.size());
+  }
+  const double tdp[3] = {tdp_loop, tdp_forward, tdp_skip};  // TdpModel keeps them private (TdpModel.hpp:25-28)
+  sr_lexicon* net = NULL;
+  if (sr_lexicon_create(scorer.handle(), lexicon.num_words(), word_off.data(), automaton.data(), lexicon.silence_idx(),
+                        tdp, tdp_model.silence_state, &net) != SR_OK) {
+    throw std::runtime_error(sr_last_error());
+  }
+  // Corpus keeps FLOAT offsets (Corpus.cpp:104); the ABI wants frame offsets
+  const size_t dim = corpus.get_features_per_timeframe();
+  std::vector<uint64_t> frame_off(corpus_size + 1, 0u);
+  for (size_t s = 0; s < corpus_size; s++) {
+    frame_off[s + 1] = corpus.get_feature_offsets(s).second / dim;
+  }
+  std::vector<uint32_t> words(frame_off[corpus_size] + 1);
+  std::vector<uint64_t> out_off(corpus_size + 1);
+  sr_search_params p = {am_threshold, word_penalty, SR_GMM_MFMA, 0};
+  const int rc = sr_recognize_batch(scorer.handle(), net, &p, *corpus.get_feature_sequence(0).first, frame_off.data(),
+                                    corpus_size, words.data(), out_off.data());
+  sr_lexicon_destroy(net);
+  if (rc != SR_OK) {
+    throw std::runtime_error(sr_last_error());
+  }
+  recognized.resize(corpus_size);
+  for (size_t s = 0; s < corpus_size; s++) {
+    recognized[s].assign(words.begin() + out_off[s], words.begin() + out_off[s + 1]);
+  }
+}
+
+#endif /* __GPU_MIXTURE_SCORER_HPP__ */

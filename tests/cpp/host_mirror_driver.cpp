@@ -1,0 +1,118 @@
+// host_mirror_driver.cpp -- drives include/sr_sietill.hpp (the C++ host mirror of the reference interface)
+// for tests/test_host_mirror.py.  Modes:
+//   edit <file>                       lines "r1 r2 .. | h1 h2 .." -> "total sub ins del" per line (CPU only)
+//   lexicon                           prints the flattened sietill digit lexicon (CPU only)
+//   run <mixset> <dim> <case.bin>     recognise + align a small corpus on the GPU, print results
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "sr_sietill.hpp"
+
+template <typename T>
+static T rd(std::istream& in) {
+  T v;
+  in.read(reinterpret_cast<char*>(&v), sizeof v);
+  return v;
+}
+
+int main(int argc, char** argv) {
+  if (argc >= 3 && !strcmp(argv[1], "edit")) {
+    std::ifstream in(argv[2]);
+    std::string line;
+    while (std::getline(in, line)) {
+      std::vector<sr::WordIdx> ref, hyp;
+      std::istringstream ss(line);
+      std::string tok;
+      bool right = false;
+      while (ss >> tok) {
+        if (tok == "|") { right = true; continue; }
+        (right ? hyp : ref).push_back(std::stoul(tok));
+      }
+      sr::EDAccumulator ed = sr::Recognizer::editDistance(ref.data(), ref.data() + ref.size(), hyp.data(), hyp.data() + hyp.size());
+      printf("%u %u %u %u\n", ed.total_count, ed.substitute_count, ed.insert_count, ed.delete_count);
+    }
+    return 0;
+  }
+  if (argc >= 2 && !strcmp(argv[1], "lexicon")) {
+    sr::Lexicon lex;  // build_sietill_lexicon, sietill/Lexicon.cpp:70-85
+    lex.add_word("[silence]", 1, 1, true);
+    const char* names[] = {"eins", "zwei", "drei", "vier", "fuenf", "sechs", "sieben", "acht", "neun", "null", "zwo"};
+    const int ns[] = {9, 9, 9, 9, 12, 9, 12, 9, 9, 9, 9};
+    for (int i = 0; i < 11; i++) lex.add_word(names[i], ns[i], 2);
+    printf("%zu %u %zu %zu\n", lex.num_words(), lex.num_states(), lex.silence_idx(), lex["sieben"]);
+    for (size_t w = 0; w < lex.num_words(); w++) {
+      auto const& a = lex.get_automaton_for_word(w);
+      for (size_t i = 0; i < a.num_states(); i++) printf("%u ", a[i]);
+      printf("\n");
+    }
+    sr::TdpModel tdp(lex.get_silence_automaton().first_state(), 3.0, 0.0, 30.0);
+    printf("%g %g %g %g %g\n", tdp.score(0, 0), tdp.score(5, 0), tdp.score(5, 1), tdp.score(5, 2), tdp.score(5, 3));
+    return 0;
+  }
+  if (argc >= 5 && !strcmp(argv[1], "run")) {
+    try {
+      const size_t dim = std::stoul(argv[3]);
+      std::ifstream in(argv[4], std::ios::binary);
+      sr::Lexicon lex;
+      const uint32_t n_words = rd<uint32_t>(in);
+      std::vector<std::pair<uint16_t, uint16_t>> ws(n_words);
+      for (auto& w : ws) { w.first = rd<uint16_t>(in); w.second = rd<uint16_t>(in); }
+      const uint32_t sil = rd<uint32_t>(in);
+      for (uint32_t w = 0; w < n_words; w++) lex.add_word("w" + std::to_string(w), ws[w].first, ws[w].second, w == sil);
+      const double tl = rd<double>(in), tf = rd<double>(in), ts = rd<double>(in), beam = rd<double>(in), wp = rd<double>(in);
+      const int kernel = (int)rd<uint32_t>(in);
+      sr::MixtureModel mm(argv[2], dim, sr::MixtureModel::NO_POOLING, true, 0, kernel);
+      sr::TdpModel tdp(lex.get_silence_automaton().first_state(), tl, tf, ts);
+      sr::Recognizer rec(lex, mm, tdp, beam, wp);
+      sr::Corpus corpus(dim);
+      const uint32_t n_utts = rd<uint32_t>(in);
+      std::vector<std::vector<float>> feats(n_utts);
+      for (uint32_t u = 0; u < n_utts; u++) {
+        const uint32_t T = rd<uint32_t>(in), n_ref = rd<uint32_t>(in);
+        std::vector<sr::WordIdx> ref(n_ref);
+        for (auto& r : ref) r = rd<uint32_t>(in);
+        feats[u].resize((size_t)T * dim);
+        in.read(reinterpret_cast<char*>(feats[u].data()), sizeof(float) * feats[u].size());
+        corpus.add_segment(feats[u].data(), T, ref);
+      }
+      sr::RecognitionStats st = rec.recognize(corpus);
+      for (auto const& h : st.hypotheses) {
+        printf("hyp");
+        for (auto w : h) printf(" %zu", w);
+        printf("\n");
+      }
+      printf("stats %u %u %u %u %zu %zu\n", st.errors.total_count, st.errors.substitute_count, st.errors.insert_count,
+             st.errors.delete_count, st.ref_words, st.sentence_errors);
+      // single-sequence entry points on utterance 0
+      std::vector<sr::WordIdx> one;
+      rec.recognizeSequence_pruned(feats[0].data(), feats[0].size() / dim, one);
+      printf("one");
+      for (auto w : one) printf(" %zu", w);
+      printf("\n");
+      mm.prepare_sequence(feats[0].data(), feats[0].size() / dim);
+      printf("score %.17g %.17g\n", mm.score(0, 0), mm.score(feats[0].size() / dim - 1, lex.num_states() - 1));
+      const uint32_t n_aut = rd<uint32_t>(in);
+      sr::MarkovAutomaton aut;
+      for (uint32_t i = 0; i < n_aut; i++) aut.states.push_back(rd<uint16_t>(in));
+      sr::Aligner al(mm, tdp);
+      std::vector<sr::AlignmentItem> ali;
+      const double c_full = al.align_sequence_full(feats[0].data(), feats[0].size() / dim, aut, ali);
+      printf("align %.17g", c_full);
+      for (auto const& it : ali) printf(" %u", it.state);
+      printf("\n");
+      const double c_pr = al.align_sequence_pruned(feats[0].data(), feats[0].size() / dim, aut, ali, 30.0);
+      printf("alignp %.17g", c_pr);
+      for (auto const& it : ali) printf(" %u", it.state);
+      printf("\n");
+    } catch (std::exception const& e) {
+      printf("error %s\n", e.what());
+      return 2;
+    }
+    return 0;
+  }
+  fprintf(stderr, "usage: see source\n");
+  return 1;
+}
