@@ -140,7 +140,8 @@ def main():
                 "peak": FP64_MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": pmc_traffic(args, n_frames),
+                "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, KB units, separate rocprofv3 --pmc passes)",
                 "launches": prof["gmm_launches"],
                 "avg_launch_ms": prof["gmm_ms"] / max(1, prof["gmm_launches"]),
                 "flops_per_frame": 4.0 * D * S * args.mix,
@@ -165,6 +166,19 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(args, n_frames):
+    """HBM bytes per GMM launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the
+    timed process); only reported when they were taken on this very workload, else null."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")
+    try:
+        z = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if args.kernel != "mfma" or z.get("workload_frames_per_launch") != n_frames or args.words != 1333 or args.mix != 32:
+        return None
+    return z["gmm_mfma_kernel"]["hbm_bytes_per_launch_corrected"]
 
 
 def usable_cores():
