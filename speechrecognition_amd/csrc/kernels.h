@@ -52,8 +52,21 @@ struct DecodeNet {
   double tdp_loop, tdp_forward, tdp_skip;
   uint32_t silence_state;
 };
+// The same network with slots sorted by type for the fast kernel (viterbi_fast.hip); ids below are positions in
+// the sorted order, every type padded to a multiple of 64 slots.
+struct FastNet {
+  uint32_t n_slots;             // padded total (multiple of 64)
+  const uint32_t* state;        // [n] emission state of the slot
+  const uint32_t* pred;         // [n] sorted id of the slot one position back | two positions back << 16
+  const uint32_t* orig;         // [n] original slot index | original index of the word's position 0 << 16; 0xFFFFFFFF = padding
+  const uint32_t* chunk_type;   // [n/64] kind | flags (viterbi_fast.hip)
+  const uint32_t* word;         // [n] word index of the slot
+  uint32_t init_slot;           // sorted id of original slot 0
+  uint32_t init_is_end;         // original slot 0 is a word end
+};
 struct DecodeArgs {
   DecodeNet net;
+  FastNet fast;
   const double* scores;         // [frames x ld] dense emission costs of this launch's frames
   uint32_t ld;
   const uint64_t* frame_off;    // [n_utts+1] global frame offsets of the corpus
@@ -68,7 +81,8 @@ struct DecodeArgs {
   uint32_t* out_count;          // [n_utts_total]
   uint32_t* out_flags;          // [n_utts_total] bit0: slow (sequential-emulation) path was taken
 };
-hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream);
+hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream);       // fast variant, then the replay variant for flagged utterances
+hipError_t launch_decode_fast(const DecodeArgs& a, hipStream_t stream);
 uint32_t decode_max_slots();
 
 // ---- forced aligners (viterbi_align.hip) ----------------------------------------------------------

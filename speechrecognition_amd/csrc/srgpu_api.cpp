@@ -122,6 +122,9 @@ struct sr_lexicon {
   uint32_t n_words = 0, n_slots = 0, silence_idx = 0, silence_state = 0;
   double tdp[3] = {0, 0, 0};
   DevBuf<uint32_t> slot_info, slot_word, word_end_slot;
+  // type-sorted copy for the fast kernel
+  DevBuf<uint32_t> f_state, f_pred, f_orig, f_type, f_word;
+  uint32_t f_n = 0, f_init = 0, f_init_end = 0;
 };
 
 namespace {
@@ -522,12 +525,50 @@ int sr_lexicon_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, c
     }
     wend[w] = b + n - 1;
   }
+  // ---- type-sorted network for the fast kernel (viterbi_fast.hip) ---------------------------------------------
+  // key = kind | silence-state << 3 | silence-word << 4 | first-state-is-silence << 5; kinds: 0 entry position 0,
+  // 1 single-position word, 2 entry position 1, 3 position 1 that is also the word end, 4 middle, 5 word end
+  std::vector<uint32_t> key(P);
+  for (uint32_t p = 0; p < P; p++) {
+    const uint32_t f = info[p];
+    const bool pos0 = f & (1u << 16), pos1 = f & (1u << 17), end = f & (1u << 18);
+    const uint32_t kind = pos0 ? (end ? 1u : 0u) : pos1 ? (end ? 3u : 2u) : (end ? 5u : 4u);
+    key[p] = kind | ((f >> 19 & 1u) << 3) | ((f >> 20 & 1u) << 4) | ((f >> 21 & 1u) << 5);
+  }
+  std::vector<uint32_t> new_id(P), f_state, f_pred, f_orig, f_type, f_word;
+  for (uint32_t k = 0; k < 64; k++) {
+    bool any = false;
+    for (uint32_t p = 0; p < P; p++) {
+      if (key[p] != k) continue;
+      any = true;
+      new_id[p] = (uint32_t)f_orig.size();
+      f_orig.push_back(p);  // completed below
+    }
+    if (!any) continue;
+    while (f_orig.size() % 64) f_orig.push_back(0xFFFFFFFFu);
+    f_type.resize(f_orig.size() / 64, k);
+  }
+  const uint32_t Pn = (uint32_t)f_orig.size();
+  if (Pn > decode_max_slots()) return fail(SR_ELIMIT, "%u type-padded trellis positions exceed the decoder's limit of %u", Pn, decode_max_slots());
+  f_state.assign(Pn, 0); f_pred.assign(Pn, 0); f_word.assign(Pn, 0);
+  for (uint32_t q = 0; q < Pn; q++) {
+    const uint32_t p = f_orig[q];
+    if (p == 0xFFFFFFFFu) { f_pred[q] = q | (q << 16); continue; }
+    const uint32_t w = sword[p], base = word_off[w], k = p - base;
+    f_state[q] = info[p] & 0xFFFFu;
+    f_word[q] = w;
+    f_pred[q] = (k >= 1 ? new_id[p - 1] : q) | ((k >= 2 ? new_id[p - 2] : q) << 16);
+    f_orig[q] = p | (base << 16);
+  }
   sr_lexicon* l = new sr_lexicon();
+  l->f_n = Pn; l->f_init = new_id[0]; l->f_init_end = (info[0] >> 18) & 1u;
   l->model = m; l->n_words = n_words; l->n_slots = P; l->silence_idx = silence_idx; l->silence_state = silence_state;
   l->tdp[0] = tdp[0]; l->tdp[1] = tdp[1]; l->tdp[2] = tdp[2];
   hipError_t e;
   if ((e = l->slot_info.upload(info.data(), P)) != hipSuccess || (e = l->slot_word.upload(sword.data(), P)) != hipSuccess ||
-      (e = l->word_end_slot.upload(wend.data(), n_words)) != hipSuccess) {
+      (e = l->word_end_slot.upload(wend.data(), n_words)) != hipSuccess || (e = l->f_state.upload(f_state.data(), Pn)) != hipSuccess ||
+      (e = l->f_pred.upload(f_pred.data(), Pn)) != hipSuccess || (e = l->f_orig.upload(f_orig.data(), Pn)) != hipSuccess ||
+      (e = l->f_type.upload(f_type.data(), Pn / 64)) != hipSuccess || (e = l->f_word.upload(f_word.data(), Pn)) != hipSuccess) {
     sr_lexicon_destroy(l);
     return fail(SR_EHIP, "lexicon upload: %s", hipGetErrorString(e));
   }
@@ -539,6 +580,7 @@ int sr_lexicon_destroy(sr_lexicon* l) {
   if (!l) return SR_OK;
   if (l->model) { (void)hipSetDevice(l->model->device); (void)hipDeviceSynchronize(); }
   l->slot_info.release(); l->slot_word.release(); l->word_end_slot.release();
+  l->f_state.release(); l->f_pred.release(); l->f_orig.release(); l->f_type.release(); l->f_word.release();
   delete l;
   return SR_OK;
 }
@@ -567,6 +609,8 @@ int sr_recognize_corpus(sr_model* m, sr_corpus* c, sr_lexicon* l, const sr_searc
   da.net.slot_info = l->slot_info.p; da.net.slot_word = l->slot_word.p; da.net.word_end_slot = l->word_end_slot.p;
   da.net.silence_word = l->silence_idx; da.net.silence_state = l->silence_state;
   da.net.tdp_loop = l->tdp[0]; da.net.tdp_forward = l->tdp[1]; da.net.tdp_skip = l->tdp[2];
+  da.fast.n_slots = l->f_n; da.fast.state = l->f_state.p; da.fast.pred = l->f_pred.p; da.fast.orig = l->f_orig.p;
+  da.fast.chunk_type = l->f_type.p; da.fast.word = l->f_word.p; da.fast.init_slot = l->f_init; da.fast.init_is_end = l->f_init_end;
   da.ld = m->ld; da.frame_off = c->d_frame_off.p;
   da.am_threshold = p->am_threshold; da.word_penalty = p->word_penalty;
   da.tb_score = c->tb_score.p; da.tb_word = c->tb_word.p; da.tb_bkp = c->tb_bkp.p;

@@ -391,22 +391,20 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream) {
   if (a.n_utts == 0) return hipSuccess;
   const uint32_t P = a.net.n_slots;
   const dim3 grid(a.n_utts);
+  // fast variant first (viterbi_fast.hip); then the replay variant, whose workgroups exit at once unless the fast
+  // one flagged their utterance (negative emission cost)
+  {
+    hipError_t e = launch_decode_fast(a, stream);
+    if (e != hipSuccess) return e;
+  }
 #define SR_LAUNCH(NT, SPT)                                                                                   \
   do {                                                                                                       \
     const size_t smem = decode_smem((NT) * (SPT));                                                           \
-    hipError_t e = hipFuncSetAttribute((const void*)decode_kernel<NT, SPT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)decode_kernel<NT, SPT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipError_t e = hipFuncSetAttribute((const void*)decode_kernel<NT, SPT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
     if (e != hipSuccess) return e;                                                                           \
-    hipLaunchKernelGGL((decode_kernel<NT, SPT, false>), grid, dim3(NT), smem, stream, a);                    \
-    if ((e = hipGetLastError()) != hipSuccess) return e;                                                     \
     hipLaunchKernelGGL((decode_kernel<NT, SPT, true>), grid, dim3(NT), smem, stream, a);                     \
     return hipGetLastError();                                                                                \
   } while (0)
-  // tuning override: SRGPU_DECODE_GEOM = threads*100 + slots_per_thread (e.g. 102404)
-  static const int geom = getenv("SRGPU_DECODE_GEOM") ? atoi(getenv("SRGPU_DECODE_GEOM")) : 0;
-  if (geom == 102404 && P <= 4096) SR_LAUNCH(1024, 4);
-  if (geom == 51208 && P <= 4096) SR_LAUNCH(512, 8);
-  if (geom == 25616 && P <= 4096) SR_LAUNCH(256, 16);
   if (P <= 64) SR_LAUNCH(64, 1);
   if (P <= 256) SR_LAUNCH(64, 4);
   if (P <= 1024) SR_LAUNCH(256, 4);
