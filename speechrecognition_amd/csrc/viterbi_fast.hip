@@ -323,7 +323,7 @@ hipError_t launch_decode_fast(const DecodeArgs& a, hipStream_t stream) {
   if (P <= 256) SR_LAUNCH(64, 4);
   if (P <= 1024) SR_LAUNCH(256, 4);
   if (P <= 2048) SR_LAUNCH(256, 8);
-  if (P <= 4096) SR_LAUNCH(512, 8);
+  if (P <= 4096) SR_LAUNCH(1024, 4);  // measured 7.5 ms vs 8.4 ms for 512 x 8 on 1000 utterances of P = 4000
   if (P <= 8192) SR_LAUNCH(1024, 8);
 #undef SR_LAUNCH
   return hipErrorInvalidValue;

@@ -254,3 +254,75 @@ def test_error_paths():
     with pytest.raises(capi.SrError) as e:
         capi.Model.from_tables([0, 1, 2], means, means + 1, np.zeros(2), np.zeros(2))
     assert e.value.code == -4  # dim > 63
+
+
+def test_cfg2_single_long_utterance(tmp_path, oracle_lib):
+    """BASELINE.json configs[1] at full size: 1000 tied states x 8 mixtures, ONE 10 000-frame utterance (the
+    latency-bound case: a single workgroup walks 10k frames).  Direct comparison with the oracle."""
+    lex = synth.make_lexicon(333, 3, 1)
+    spec = synth.make_mixset(lex.n_states, 8, 39, seed=23)
+    mp = str(tmp_path / "cfg2.mix")
+    synth.write_mixset(mp, spec)
+    feats = synth.make_features(10000, 39, seed=24)
+    off = np.array([0, 10000], dtype=np.uint64)
+    word_off, automaton, sil_state = lex.flatten()
+    o = oracle_lib.Oracle(mp, 39, lex, am_threshold=200.0)
+    want_words, (ws, ww, wb) = o.decode(feats, traceback=True)
+    with capi.Model.from_mixset(mp, 39) as m:
+        lexh = m.lexicon(word_off, automaton, lex.silence_idx, (3.0, 0.0, 30.0), sil_state)
+        corpus = m.upload(feats, off)
+        words, woff, (tbs, tbw, tbb) = corpus.recognize(lexh, 200.0, 10.0, capi.GMM_EXACT, traceback=True)
+        assert np.array_equal(words, want_words)
+        assert np.array_equal(tbw, ww) and np.array_equal(tbb, wb) and np.array_equal(tbs.view(np.uint64), ws.view(np.uint64))
+        words, woff = corpus.recognize(lexh, 200.0, 10.0, capi.GMM_MFMA)
+        assert np.array_equal(words, want_words)
+        # aligner over the long utterance: 40 words
+        rng = np.random.default_rng(25)
+        aut = [sil_state]
+        for w in rng.integers(1, lex.n_words, size=40):
+            aut += list(automaton[word_off[w]:word_off[w + 1]]) + [sil_state]
+        aut = np.asarray(aut, dtype=np.uint16)
+        dense = o.score_matrix(feats, n_threads=8)
+        st, cost = corpus.align([aut], (3.0, 0.0, 30.0), sil_state, capi.GMM_EXACT)
+        wst, wcost = o.align_full(feats, aut, dense=dense)
+        assert np.array_equal(st, wst) and cost[0] == wcost
+        st, cost = corpus.align([aut], (3.0, 0.0, 30.0), sil_state, capi.GMM_EXACT, pruning_threshold=60.0)
+        wst, wcost = o.align_pruned(feats, aut, 60.0, dense=dense)
+        assert np.array_equal(st, wst) and cost[0] == wcost
+        corpus.close()
+        lexh.close()
+    o.close()
+
+
+def test_cfg5_model_size(tmp_path, oracle_lib):
+    """BASELINE.json configs[4] model size: 8000 states x 64 mixtures (512 000 densities), 2666 three-state words
+    plus one four-state word -> 8003 trellis positions (the 1024 x 8 decoder geometry).  A short utterance
+    directly against the oracle, a longer batch through exact-vs-MFMA equality."""
+    lex = synth.make_lexicon(2666, 3, 1, extra_states_last=1)
+    assert lex.n_states == 8000
+    spec = synth.make_mixset(lex.n_states, 64, 39, seed=29)
+    mp = str(tmp_path / "cfg5.mix")
+    synth.write_mixset(mp, spec)
+    word_off, automaton, sil_state = lex.flatten()
+    short = synth.make_features(24, 39, seed=30)
+    o = oracle_lib.Oracle(mp, 39, lex, am_threshold=200.0)
+    want_scores = o.score_matrix(short, n_threads=8)
+    want_words = o.decode(short, dense=want_scores)
+    o.close()
+    feats, off = synth.make_batch(6, 120, 200, 39, seed=31)
+    with capi.Model.from_mixset(mp, 39) as m:
+        assert m.n_densities == 512000
+        got = m.score_frames(short, capi.GMM_EXACT)
+        assert np.array_equal(got.view(np.uint64), want_scores.view(np.uint64))
+        _assert_scores_close(m.score_frames(short, capi.GMM_MFMA), want_scores)
+        lexh = m.lexicon(word_off, automaton, lex.silence_idx, (3.0, 0.0, 30.0), sil_state)
+        c1 = m.upload(short, np.array([0, len(short)], dtype=np.uint64))
+        w, _ = c1.recognize(lexh, 200.0, 10.0, capi.GMM_EXACT)
+        assert np.array_equal(w, want_words)
+        c1.close()
+        corpus = m.upload(feats, off)
+        wa, oa = corpus.recognize(lexh, 200.0, 10.0, capi.GMM_MFMA)
+        wb, ob = corpus.recognize(lexh, 200.0, 10.0, capi.GMM_EXACT)
+        assert np.array_equal(wa, wb) and np.array_equal(oa, ob) and len(wa) > 0
+        corpus.close()
+        lexh.close()
