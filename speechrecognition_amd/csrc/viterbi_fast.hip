@@ -128,27 +128,26 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
     a.tb_score[tb0] = 0.0; a.tb_word[tb0] = 0; a.tb_bkp[tb0] = 0;
   }
   if (tid < 4 && init_is_end) e_first[4 + tid] = 0;
-  double am_s0[SPT], am_s1[SPT];  // emission gathers two frames ahead (set f&1 holds frame f)
+  double am_n[SPT];  // emission gathers one frame ahead: frame t+1's costs are issued at the top of frame t
 #pragma unroll
   for (int i = 0; i < SPT; i++) {
     const uint32_t p = tid + i * NT;
-    am_s1[i] = T > 0 ? row0[st[i]] : 0.0;
-    am_l[p] = am_s1[i];
-    am_s0[i] = T > 1 ? row0[a.ld + st[i]] : 0.0;
+    am_n[i] = T > 0 ? row0[st[i]] : 0.0;
+    am_l[p] = am_n[i];
   }
   __syncthreads();
 
 #ifdef SR_DECODE_STAMPS
   unsigned long long stamp_sum[6] = {0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
 #endif
-  auto frame = [&](const uint32_t t, double (&am_issue)[SPT], double (&am_consume)[SPT]) -> bool {
+  auto frame = [&](const uint32_t t) -> bool {
     const uint32_t* ef_cur = e_first + 4 * (t & 1);
     uint32_t* ef_nxt = e_first + 4 * ((t + 1) & 1);
     const uint32_t bkp_new = (t - 1) & 0xFFFFu;
-    if (t + 2 <= T) {
-      const double* rown = row0 + (uint64_t)(t + 1) * a.ld;
+    if (t + 1 <= T) {
+      const double* rown = row0 + (uint64_t)t * a.ld;  // frame t+1
 #pragma unroll
-      for (int i = 0; i < SPT; i++) am_issue[i] = rown[st[i]];
+      for (int i = 0; i < SPT; i++) am_n[i] = rown[st[i]];
     }
 
     SR_STAMP(0);
@@ -251,7 +250,7 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
       if (v > limit) v = kInfF;  // :194-196
       sc[p] = v;
       bk[p] = (uint16_t)nb[i];
-      am_l[p] = am_consume[i];
+      am_l[p] = am_n[i];
       if (kind == kE0S || kind == kE1E || kind == kME) {
         if (we_alive && v <= near) {
           const uint32_t o = og[i] & 0xFFFFu;
@@ -270,10 +269,8 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
     return false;
   };
 
-  for (uint32_t t = 1; t <= T; t += 2) {
-    if (frame(t, am_s1, am_s0)) return;
-    if (t + 1 <= T && frame(t + 1, am_s0, am_s1)) return;
-  }
+  for (uint32_t t = 1; t <= T; t++)
+    if (frame(t)) return;
 
   // ---- traceback (Recognizer.cpp:222-231) --------------------------------------------------------------------
   __threadfence();
