@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--beam", type=float, default=200.0)
     ap.add_argument("--kernel", choices=["mfma", "exact"], default="mfma")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals "
+                    "where several ranks share one GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the cpu_baseline leg")
     return ap.parse_args()
 
@@ -59,9 +61,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     distributed = world > 1
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    device = local_rank if args.dist_backend == "nccl" else local_rank % max(1, n_dev)  # gloo rehearsal may share a GPU
+    torch.cuda.set_device(device)
     if distributed:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend=args.dist_backend)
 
     from speechrecognition_amd import capi, synth
 
@@ -78,7 +85,7 @@ def main():
     word_off, automaton, sil_state = lex.flatten()
     kernel = capi.GMM_MFMA if args.kernel == "mfma" else capi.GMM_EXACT
 
-    model = capi.Model.from_mixset(mixset_path, D, capi.POOL_NONE, True, device=local_rank)
+    model = capi.Model.from_mixset(mixset_path, D, capi.POOL_NONE, True, device=device)
     lexh = model.lexicon(word_off, automaton, lex.silence_idx, tdp, sil_state)
     corpus = model.upload(feats, frame_off)  # inputs resident in HBM before timing starts
 
@@ -105,7 +112,7 @@ def main():
     from speechrecognition_amd import sharding
 
     elapsed, total_frames = sharding.reduce_timing(elapsed, n_frames, dist if distributed else None,
-                                                   torch.device("cuda", local_rank))
+                                                   torch.device("cuda", device) if args.dist_backend == "nccl" else None)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
