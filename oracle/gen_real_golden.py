@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Real-speech golden vectors: the REFERENCE's trainer, corpus reader and recogniser on real
+SieTill cepstra (/root/reference/data/new_features, the reference's own corpus lists), build container only.
+
+  1. a training subset goes through the reference's Corpus::read (delta / normalisation, Corpus.cpp:89-111) and
+     Trainer::train (linear segmentation, splitting, Viterbi re-alignment, Training.cpp:44-235) -> MIXSET v2 models
+     for mixture pooling and for no pooling;
+  2. a test subset is decoded (Recognizer::recognizeSequence_pruned) and force-aligned (Aligner) by the reference
+     with those models at a wide and a tight beam.
+
+Committed as data: the processed features of the test utterances, the two model files, and the reference's
+outputs -> tests/golden_real/.  On real speech the beam prunes hard and emission costs go negative, which the
+synthetic fixtures cannot provide.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import pyoracle as po  # noqa: E402
+from speechrecognition_amd import synth  # noqa: E402
+
+REF = "/root/reference/src/sietill"
+FEATS = "/root/reference/data/new_features/"
+OUT = os.path.join(ROOT, "tests", "golden_real")
+TDP = (3.0, 0.0, 30.0)
+
+
+def subset(path, speakers, per_speaker):
+    segs = json.load(open(path))["segments"]
+    out, count = [], {}
+    for s in segs:
+        sp = s["speaker"]
+        if sp in speakers and count.get(sp, 0) < per_speaker and os.path.exists(FEATS + s["name"] + ".mm2"):
+            out.append(s)
+            count[sp] = count.get(sp, 0) + 1
+    return out
+
+
+def base_config(corpus_json, extra):
+    cfg = {
+        "verbosity": "noLog", "corpus": corpus_json, "feature-path": FEATS,
+        "normalization-path": os.path.join(REF, "Normalization.bin"), "energy-max-norm": True,
+        "sample-rate": 8000, "window-shift": 10, "window-size": 25, "dft-length": 1024,
+        "n-features-file": 12, "n-features-first": 12, "n-features-second": 1, "deriv-step": 3,
+        "tdp-loop": TDP[0], "tdp-forward": TDP[1], "tdp-skip": TDP[2], "max-approx": True,
+    }
+    cfg.update(extra)
+    return cfg
+
+
+def main():
+    assert po.reference_available()
+    os.makedirs(OUT, exist_ok=True)
+    L = C.CDLL(po.REF_SO)
+    L.ref_real_train.argtypes = [C.c_char_p, C.c_int, C.c_int]
+    L.ref_corpus_open.restype = C.c_void_p
+    L.ref_corpus_open.argtypes = [C.c_char_p]
+    for f in ("ref_corpus_size", "ref_corpus_dim"):
+        getattr(L, f).restype, getattr(L, f).argtypes = C.c_size_t, [C.c_void_p]
+    L.ref_corpus_frames.restype, L.ref_corpus_frames.argtypes = C.c_size_t, [C.c_void_p, C.c_size_t]
+    L.ref_corpus_get.restype, L.ref_corpus_get.argtypes = C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.ref_corpus_close.argtypes = [C.c_void_p]
+
+    tmp = tempfile.mkdtemp()
+    train_spk = [f"{i:03d}" for i in range(0, 400)]
+    train = subset(os.path.join(REF, "corpora", "corpus_train.json"), set(train_spk), 10)
+    test_all = json.load(open(os.path.join(REF, "corpora", "corpus_test.json")))["segments"]
+    rng = np.random.default_rng(11)
+    test = [test_all[i] for i in sorted(rng.choice(len(test_all), size=24, replace=False))
+            if os.path.exists(FEATS + test_all[i]["name"] + ".mm2")][:16]
+    print(f"train {len(train)} utterances, test {len(test)}")
+    tj, ej = os.path.join(tmp, "train.json"), os.path.join(tmp, "test.json")
+    json.dump({"segments": train}, open(tj, "w"))
+    json.dump({"segments": test}, open(ej, "w"))
+
+    models = {}
+    for pname, pool in (("mixture", po.POOL_MIXTURE), ("none", po.POOL_NONE)):
+        prefix = os.path.join(tmp, f"model-{pname}-")
+        cfg = base_config(tj, {"action": "train", "pooling": pname, "min-obs": 1, "num-splits": 3, "num-aligns": 1,
+                               "num-estimates": 2, "num-max-aligns": 1, "alignment-pruning": True, "pruning-threshold": 120.0,
+                               "realign": True, "mixture-path": prefix})
+        cp = os.path.join(tmp, f"train-{pname}.json")
+        json.dump(cfg, open(cp, "w"))
+        L.ref_real_train(cp.encode(), pool, 1)
+        models[pname] = (prefix + "3.mix", pool)
+
+    # processed test features + reference transcriptions via the reference's Corpus
+    cp = os.path.join(tmp, "test-corpus.json")
+    json.dump(base_config(ej, {"action": "recognize"}), open(cp, "w"))
+    h = L.ref_corpus_open(cp.encode())
+    dim = L.ref_corpus_dim(h)
+    n = L.ref_corpus_size(h)
+    feats, frame_off, refs = [], [0], []
+    for s in range(n):
+        T = L.ref_corpus_frames(h, s)
+        f = np.zeros((T, dim), dtype=np.float32)
+        w = np.zeros(64, dtype=np.uint64)
+        nw = L.ref_corpus_get(h, s, f.ctypes.data, w.ctypes.data)
+        feats.append(f)
+        frame_off.append(frame_off[-1] + T)
+        refs.append(w[:nw].astype(np.uint32))
+    L.ref_corpus_close(h)
+    feats_cat = np.concatenate(feats)
+    lex = synth.sietill_lexicon()
+    word_off, automaton, sil = lex.flatten()
+
+    out = dict(dim=dim, feats=feats_cat, frame_off=np.asarray(frame_off, dtype=np.uint64),
+               ref_flat=np.concatenate(refs), ref_off=np.cumsum([0] + [len(r) for r in refs]).astype(np.uint32),
+               names=np.asarray([t["name"] for t in test]), tdp=np.asarray(TDP))
+    for pname, (mix_path, pool) in models.items():
+        out[f"model_{pname}"] = np.frombuffer(open(mix_path, "rb").read(), dtype=np.uint8)
+        for tag, beam, wp, athr in (("wide", 200.0, 80.0, 120.0), ("tight", 40.0, 30.0, 25.0)):
+            rc = os.path.join(tmp, f"rec-{pname}-{tag}.json")
+            synth.write_config(rc, mix_path, tdp=TDP, am_threshold=beam, word_penalty=wp)
+            ref = po.Reference(rc, dim, lex, pooling=pool)
+            orc = po.Oracle(mix_path, dim, lex, tdp=TDP, am_threshold=beam, word_penalty=wp, pooling=pool)
+            words, costs_f, costs_p, st_f, st_p, errs, neg = [], [], [], [], [], np.zeros(4, np.int64), 0
+            for f, r in zip(feats, refs):
+                w = ref.decode(f)
+                assert np.array_equal(w, orc.decode(f)), (pname, tag)
+                words.append(w)
+                errs += ref.edit_distance(r, w).astype(np.int64)
+                aut = [sil]
+                for x in r:
+                    aut += list(automaton[word_off[x]:word_off[x + 1]]) + [sil]
+                aut = np.asarray(aut, dtype=np.uint16)
+                s1, c1 = ref.align_full(f, aut)
+                s2, c2 = ref.align_pruned(f, aut, athr)
+                o1, oc1 = orc.align_full(f, aut)
+                o2, oc2 = orc.align_pruned(f, aut, athr)
+                assert np.array_equal(s1, o1) and c1 == oc1 and np.array_equal(s2, o2) and c2 == oc2
+                st_f.append(s1); costs_f.append(c1); st_p.append(s2); costs_p.append(c2)
+            sc = ref.score_matrix(feats[0])
+            assert np.array_equal(sc.view(np.uint64), orc.score_matrix(feats[0]).view(np.uint64))
+            neg = float((sc < 0).mean())
+            key = f"{pname}_{tag}"
+            out[f"{key}_beam"], out[f"{key}_wp"], out[f"{key}_athr"] = beam, wp, athr
+            out[f"{key}_words"] = np.concatenate(words).astype(np.uint32) if sum(map(len, words)) else np.zeros(0, np.uint32)
+            out[f"{key}_word_off"] = np.cumsum([0] + [len(w) for w in words]).astype(np.uint32)
+            out[f"{key}_align_full"] = np.concatenate(st_f)
+            out[f"{key}_align_full_cost"] = np.asarray(costs_f)
+            out[f"{key}_align_pruned"] = np.concatenate(st_p)
+            out[f"{key}_align_pruned_cost"] = np.asarray(costs_p)
+            out[f"{key}_errors"] = errs
+            if tag == "wide" and pname == "none":
+                out[f"{pname}_scores_utt0"] = sc
+            nd = orc.L.orc_model_num_densities(orc.h)
+            print(f"{key}: densities {nd}, WER {100.0 * errs[0] / len(out['ref_flat']):.1f}% "
+                  f"(S/I/D {errs[1]}/{errs[2]}/{errs[3]}), negative scores {100 * neg:.1f}%")
+            ref.close(); orc.close()
+    np.savez_compressed(os.path.join(OUT, "sietill_real.npz"), **out)
+    print("wrote", os.path.getsize(os.path.join(OUT, "sietill_real.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

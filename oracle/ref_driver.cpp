@@ -24,8 +24,13 @@
 #include "Config.hpp"
 #include "Lexicon.hpp"
 #include "Mixtures.hpp"
+#include "Corpus.hpp"
 #include "Recognizer.hpp"
+#include "SignalAnalysis.hpp"
 #include "TdpModel.hpp"
+#include "Training.hpp"
+
+#include <fstream>
 
 namespace {
 struct RefCtx {
@@ -137,6 +142,69 @@ double ref_align_full(void* h, const float* feats, size_t T, const uint16_t* ref
 double ref_align_pruned(void* h, const float* feats, size_t T, const uint16_t* ref, size_t N, double thr,
                         uint16_t* out_states) {
   return run_align(static_cast<RefCtx*>(h), feats, T, ref, N, 1, thr, out_states);
+}
+
+// ---- real-data helpers (oracle/gen_real_golden.py): the reference's own corpus reader, front-end
+// post-processing (Corpus::read -> SignalAnalysis::process_features, Corpus.cpp:89-111) and GMM trainer
+// (Trainer::train, Training.cpp:44-235) on SieTill features from /root/reference/data/new_features.
+
+namespace {
+struct RefCorpus {
+  std::unique_ptr<Configuration> config;
+  Lexicon lexicon;
+  std::unique_ptr<SignalAnalysis> analyzer;
+  std::unique_ptr<CorpusDescription> description;
+  Corpus corpus;
+};
+
+RefCorpus* open_corpus(const char* config_path) {
+  RefCorpus* c = new RefCorpus();
+  c->config.reset(new Configuration(std::string(config_path)));
+  c->lexicon = build_sietill_lexicon();
+  c->description.reset(new CorpusDescription(*c->config));
+  c->description->read(c->lexicon);
+  c->analyzer.reset(new SignalAnalysis(*c->config));
+  const ParameterString paramNormalizationPath("normalization-path", "");
+  const ParameterString paramFeaturePath("feature-path", "");
+  std::string norm = paramNormalizationPath(*c->config);
+  if (norm.size() > 0) {
+    std::ifstream in(norm.c_str(), std::ios_base::in);
+    c->analyzer->read_normalization_file(in);  // SieTill.cpp:83-90
+  }
+  c->corpus.read(*c->description, paramFeaturePath(*c->config), *c->analyzer);
+  return c;
+}
+}  // namespace
+
+// SieTill.cpp:107-124 with action "train"; pooling as MixtureModel::VarianceModel
+int ref_real_train(const char* config_path, int pooling, int max_approx) {
+  RefCorpus* c = open_corpus(config_path);
+  TdpModel tdp_model(*c->config, c->lexicon.get_silence_automaton()[0ul]);
+  MixtureModel mixtures(*c->config, c->analyzer->n_features_total, c->lexicon.num_states(),
+                        static_cast<MixtureModel::VarianceModel>(pooling), max_approx != 0);
+  Trainer trainer(*c->config, c->lexicon, mixtures, tdp_model, max_approx != 0);
+  trainer.train(c->corpus);
+  delete c;
+  return 0;
+}
+
+void* ref_corpus_open(const char* config_path) { return open_corpus(config_path); }
+void ref_corpus_close(void* h) { delete static_cast<RefCorpus*>(h); }
+size_t ref_corpus_size(void* h) { return static_cast<RefCorpus*>(h)->corpus.get_corpus_size(); }
+size_t ref_corpus_dim(void* h) { return static_cast<RefCorpus*>(h)->corpus.get_features_per_timeframe(); }
+size_t ref_corpus_frames(void* h, size_t s) {
+  std::pair<FeatureIter, FeatureIter> f = static_cast<RefCorpus*>(h)->corpus.get_feature_sequence(s);
+  return f.second - f.first;
+}
+// copies the processed features of segment s and its reference word sequence; returns the word count
+size_t ref_corpus_get(void* h, size_t s, float* feats, uint64_t* words) {
+  RefCorpus* c = static_cast<RefCorpus*>(h);
+  std::pair<FeatureIter, FeatureIter> f = c->corpus.get_feature_sequence(s);
+  std::memcpy(feats, *f.first, sizeof(float) * (f.second - f.first) * c->corpus.get_features_per_timeframe());
+  std::pair<WordIter, WordIter> w = c->corpus.get_word_sequence(s);
+  size_t n = 0;
+  for (WordIter it = w.first; it != w.second; ++it) words[n++] = *it;
+  return n;
 }
 
 }  // extern "C"
