@@ -11,6 +11,7 @@
 //   sr::Corpus                 Corpus (feature store)       sietill/Corpus.hpp:55-84
 //   sr::Recognizer             Recognizer                   sietill/Recognizer.hpp:91-132
 //   sr::Aligner                Aligner                      sietill/Alignment.hpp:19-63
+//   sr::Trainer (re-alignment) Trainer::train's align loop   sietill/Training.cpp:163-184, :239-253, :585-612
 //
 // Differences, all forced by the device boundary: features are passed as (pointer, frame count)
 // instead of FeatureIter pairs; MixtureModel::prepare_sequence really does work (it fills the dense
@@ -348,6 +349,81 @@ class Aligner {
     for (size_t t = 0; t < T; t++) { alignment[t].state = states[t]; alignment[t].weight = 1; alignment[t].count = 1; }
     return cost;
   }
+  MixtureModel& mixtures_;
+  TdpModel tdp_;
+};
+
+// ---- the training-side callers of the path (Training.hpp:18-107): NOT the EM trainer, only the two loops of
+// Trainer::train that run the scorer and the aligner over the whole corpus -- re-alignment (Training.cpp:163-184)
+// and the average acoustic score along the alignment (calc_am_score, :585-612) -- each as one device pass.
+class Trainer {
+ public:
+  Trainer(Lexicon const& lexicon, MixtureModel& mixtures, TdpModel const& tdp_model, double pruning_threshold = 50.0,
+          bool alignment_pruning = true)
+      : pruning_threshold_(pruning_threshold), alignment_pruning_(alignment_pruning), lexicon_(lexicon),
+        mixtures_(mixtures), tdp_(tdp_model) {}
+
+  // Trainer::build_segment_automaton (Training.cpp:238-253): sil w1 sil w2 ... sil
+  MarkovAutomaton build_segment_automaton(const WordIdx* segment_begin, const WordIdx* segment_end) const {
+    std::vector<MarkovAutomaton const*> automata;
+    for (const WordIdx* it = segment_begin; it != segment_end; ++it) {
+      automata.push_back(&lexicon_.get_silence_automaton());
+      automata.push_back(&lexicon_.get_automaton_for_word(*it));
+    }
+    automata.push_back(&lexicon_.get_silence_automaton());
+    return MarkovAutomaton::concat(automata);
+  }
+
+  // the re-alignment loop of Trainer::train (Training.cpp:163-184) over every segment of the corpus;
+  // alignment gets one item per corpus frame, costs (optional) the per-segment path costs
+  void realign(Corpus const& corpus, std::vector<AlignmentItem>& alignment, std::vector<double>* costs = nullptr) {
+    const size_t n = corpus.get_corpus_size();
+    std::vector<uint16_t> automata;
+    std::vector<uint64_t> aut_off(1, 0);
+    for (size_t s = 0; s < n; s++) {
+      auto w = corpus.get_word_sequence(s);
+      MarkovAutomaton a = build_segment_automaton(w.first, w.second);
+      automata.insert(automata.end(), a.states.begin(), a.states.end());
+      aut_off.push_back(automata.size());
+    }
+    const uint64_t F = corpus.get_total_frame_count();
+    const double tdp[3] = {tdp_.tdp_loop, tdp_.tdp_forward, tdp_.tdp_skip};
+    sr_corpus* c = nullptr;
+    check(sr_corpus_upload(mixtures_.handle(), corpus.features(), corpus.frame_offsets(), (uint32_t)n, &c));
+    std::vector<uint16_t> states(std::max<uint64_t>(F, 1));
+    std::vector<double> cost(std::max<size_t>(n, 1));
+    const int rc = alignment_pruning_
+                       ? sr_align_corpus_pruned(mixtures_.handle(), c, automata.data(), aut_off.data(), tdp, tdp_.silence_state,
+                                                pruning_threshold_, mixtures_.gmm_kernel, states.data(), cost.data())
+                       : sr_align_corpus(mixtures_.handle(), c, automata.data(), aut_off.data(), tdp, tdp_.silence_state,
+                                         mixtures_.gmm_kernel, states.data(), cost.data());
+    sr_corpus_destroy(c);
+    check(rc);
+    alignment.assign(F, AlignmentItem());
+    for (uint64_t t = 0; t < F; t++) { alignment[t].state = states[t]; alignment[t].weight = 1; alignment[t].count = 1; }
+    if (costs) costs->assign(cost.begin(), cost.begin() + n);
+  }
+
+  // Trainer::calc_am_score (Training.cpp:585-612): sequential sum of score(frame, aligned state) / frames
+  double calc_am_score(Corpus const& corpus, std::vector<AlignmentItem> const& alignment) {
+    const uint64_t F = corpus.get_total_frame_count();
+    std::vector<uint16_t> states(std::max<uint64_t>(F, 1));
+    for (uint64_t t = 0; t < F; t++) states[t] = alignment[t].state;
+    std::vector<double> per_frame(std::max<uint64_t>(F, 1));
+    sr_corpus* c = nullptr;
+    check(sr_corpus_upload(mixtures_.handle(), corpus.features(), corpus.frame_offsets(), (uint32_t)corpus.get_corpus_size(), &c));
+    const int rc = sr_path_scores_corpus(mixtures_.handle(), c, states.data(), mixtures_.gmm_kernel, per_frame.data());
+    sr_corpus_destroy(c);
+    check(rc);
+    double total_score = 0.0;
+    for (uint64_t t = 0; t < F; t++) total_score += per_frame[t];
+    return total_score / F;
+  }
+
+ private:
+  const double pruning_threshold_;
+  const bool alignment_pruning_;
+  Lexicon const& lexicon_;
   MixtureModel& mixtures_;
   TdpModel tdp_;
 };

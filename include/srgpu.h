@@ -131,6 +131,12 @@ SR_API int sr_align_corpus_pruned(sr_model* m, sr_corpus* c, const uint16_t* aut
                            const double tdp[3], uint16_t silence_state, double pruning_threshold, int gmm_kernel,
                            uint16_t* out_states, double* out_cost);
 
+/* ---- training-side caller of the scorer: Trainer::calc_am_score (Training.cpp:585-612) -----------------------
+ * out[t] = MixtureModel::score(frame t, states[t]) for every frame of the corpus, i.e. the emission cost along
+ * a given state path (an alignment from sr_align_corpus*).  The reference's average AM score is the sequential
+ * sum of out[] divided by the frame count; the sum is left to the host so that it keeps the reference's order. */
+SR_API int sr_path_scores_corpus(sr_model* m, sr_corpus* c, const uint16_t* states, int gmm_kernel, double* out);
+
 /* ---- measurement --------------------------------------------------------------------------------
  * When enabled, every kernel launch of this model handle is bracketed by HIP events on the
  * launch stream; sr_profile_read() synchronises and returns accumulated device times. */

@@ -21,7 +21,7 @@ POOL_GLOBAL, POOL_MIXTURE, POOL_NONE = 0, 1, 2
 SYMBOLS = [
     "sr_last_error", "sr_device_count", "sr_model_create", "sr_model_load_mixset", "sr_model_destroy", "sr_model_info",
     "sr_corpus_upload", "sr_corpus_destroy", "sr_score_corpus", "sr_score_frames", "sr_lexicon_create",
-    "sr_lexicon_destroy", "sr_recognize_corpus", "sr_recognize_batch", "sr_align_corpus", "sr_align_corpus_pruned",
+    "sr_lexicon_destroy", "sr_recognize_corpus", "sr_recognize_batch", "sr_align_corpus", "sr_align_corpus_pruned", "sr_path_scores_corpus",
     "sr_profile_enable", "sr_profile_reset", "sr_profile_read",
 ]
 
@@ -69,6 +69,7 @@ def lib():
         L.sr_recognize_batch.argtypes = [vp, vp, C.POINTER(SearchParams), vp, vp, u32, vp, vp]
         L.sr_align_corpus.argtypes = [vp, vp, vp, vp, C.POINTER(dbl * 3), C.c_uint16, i32, vp, vp]
         L.sr_align_corpus_pruned.argtypes = [vp, vp, vp, vp, C.POINTER(dbl * 3), C.c_uint16, dbl, i32, vp, vp]
+        L.sr_path_scores_corpus.argtypes = [vp, vp, vp, i32, vp]
         L.sr_profile_enable.argtypes = [vp, i32]
         L.sr_profile_reset.argtypes = [vp]
         L.sr_profile_read.argtypes = [vp, C.POINTER(Profile)]
@@ -209,6 +210,13 @@ class Corpus:
             _check(lib().sr_align_corpus_pruned(self.model.h, self.h, _ptr(flat), _ptr(off), C.byref(t3), silence_state,
                                                 float(pruning_threshold), kernel, _ptr(states), _ptr(cost)))
         return states[: self.n_frames], cost[: self.n_utts]
+
+    def path_scores(self, states, kernel=GMM_MFMA):
+        """Emission cost along a state path (one state per frame): Trainer::calc_am_score's summands."""
+        states = np.ascontiguousarray(states, dtype=np.uint16)
+        out = np.zeros(max(self.n_frames, 1), dtype=np.float64)
+        _check(lib().sr_path_scores_corpus(self.model.h, self.h, _ptr(states), kernel, _ptr(out)))
+        return out[: self.n_frames]
 
 
 class Lexicon:

@@ -107,4 +107,8 @@ hipError_t launch_align_full(const AlignArgs& a, hipStream_t stream);
 hipError_t launch_align_pruned(const AlignArgs& a, hipStream_t stream);
 uint32_t align_max_positions();
 
+// out[f] = scores[(f - frame_base) * ld + states[f]] for f in [f0, f1)  (Trainer::calc_am_score, Training.cpp:605)
+hipError_t launch_path_scores(const double* scores, uint32_t ld, uint64_t frame_base, uint64_t f0, uint64_t f1,
+                              const uint16_t* states, double* out, hipStream_t stream);
+
 }  // namespace srgpu

@@ -114,7 +114,7 @@ struct sr_corpus {
   DevBuf<uint16_t> automata, out_states;
   DevBuf<uint64_t> aut_off, bp_off;
   DevBuf<uint8_t> backptr;
-  DevBuf<double> out_cost;
+  DevBuf<double> out_cost, path_scores;
 };
 
 struct sr_lexicon {
@@ -441,7 +441,7 @@ int sr_corpus_destroy(sr_corpus* c) {
   if (c->model) { (void)hipSetDevice(c->model->device); (void)hipDeviceSynchronize(); }
   c->feats.release(); c->d_frame_off.release(); c->tb_score.release(); c->tb_word.release(); c->tb_bkp.release();
   c->out_words.release(); c->out_count.release(); c->out_flags.release(); c->automata.release(); c->out_states.release();
-  c->aut_off.release(); c->bp_off.release(); c->backptr.release(); c->out_cost.release();
+  c->aut_off.release(); c->bp_off.release(); c->backptr.release(); c->out_cost.release(); c->path_scores.release();
   delete c;
   return SR_OK;
 }
@@ -734,6 +734,30 @@ int sr_align_corpus_pruned(sr_model* m, sr_corpus* c, const uint16_t* automata, 
                            const double tdp[3], uint16_t silence_state, double pruning_threshold, int gmm_kernel,
                            uint16_t* out_states, double* out_cost) {
   return align_common(m, c, automata, aut_off, tdp, silence_state, pruning_threshold, true, gmm_kernel, out_states, out_cost);
+}
+
+int sr_path_scores_corpus(sr_model* m, sr_corpus* c, const uint16_t* states, int gmm_kernel, double* out) {
+  int rc = check_model(m);
+  if (rc) return rc;
+  if (!c || c->model != m) return fail(SR_EINVAL, "corpus does not belong to this model");
+  const uint64_t F = c->n_frames;
+  if (F == 0) return SR_OK;
+  if (!states || !out) return fail(SR_EINVAL, "null argument");
+  for (uint64_t f = 0; f < F; f++)
+    if (states[f] >= m->n_states) return fail(SR_EINVAL, "frame %llu: state %u >= n_states", (unsigned long long)f, states[f]);
+  HIP_TRY(c->out_states.upload(states, F));
+  HIP_TRY(c->path_scores.ensure(F));
+  const size_t step = m->chunk_frames;
+  HIP_TRY(m->scores[0].ensure((size_t)std::min<uint64_t>(F, step) * m->ld));
+  for (uint64_t f = 0; f < F; f += step) {
+    const uint64_t n = std::min<uint64_t>(step, F - f);
+    if ((rc = launch_scoring(m, c->feats.p + f * m->dim, n, gmm_kernel, m->scores[0].p))) return rc;
+    HIP_TRY(launch_path_scores(m->scores[0].p, m->ld, f, f, f + n, c->out_states.p, c->path_scores.p, m->s_gmm));
+  }
+  HIP_TRY(hipStreamSynchronize(m->s_gmm));
+  HIP_TRY(hipMemcpy(out, c->path_scores.p, sizeof(double) * F, hipMemcpyDeviceToHost));
+  if (m->profiling) m->prof.frames += F;
+  return SR_OK;
 }
 
 int sr_profile_enable(sr_model* m, int on) {

@@ -180,6 +180,20 @@ __global__ __launch_bounds__(kAlignThreads) void align_pruned_kernel(AlignArgs a
   }
 }
 
+__global__ void path_scores_kernel(const double* scores, uint32_t ld, uint64_t frame_base, uint64_t f0, uint64_t f1,
+                                   const uint16_t* states, double* out) {
+  const uint64_t f = f0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f < f1) out[f] = scores[(f - frame_base) * ld + states[f]];
+}
+
+hipError_t launch_path_scores(const double* scores, uint32_t ld, uint64_t frame_base, uint64_t f0, uint64_t f1,
+                              const uint16_t* states, double* out, hipStream_t stream) {
+  if (f1 <= f0) return hipSuccess;
+  hipLaunchKernelGGL(path_scores_kernel, dim3((unsigned)((f1 - f0 + 255) / 256)), dim3(256), 0, stream, scores, ld, frame_base,
+                     f0, f1, states, out);
+  return hipGetLastError();
+}
+
 uint32_t align_max_positions() { return 8192; }
 
 hipError_t launch_align_full(const AlignArgs& a, hipStream_t stream) {

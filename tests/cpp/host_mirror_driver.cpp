@@ -107,6 +107,16 @@ int main(int argc, char** argv) {
       printf("alignp %.17g", c_pr);
       for (auto const& it : ali) printf(" %u", it.state);
       printf("\n");
+      // training-side callers: corpus-wide re-alignment against the transcriptions + average AM score
+      sr::Trainer trainer(lex, mm, tdp, 40.0, true);
+      std::vector<sr::AlignmentItem> corpus_ali;
+      std::vector<double> costs;
+      trainer.realign(corpus, corpus_ali, &costs);
+      printf("realign");
+      for (double c : costs) printf(" %.17g", c);
+      printf("\nrealign_states");
+      for (auto const& it : corpus_ali) printf(" %u", it.state);
+      printf("\namscore %.17g\n", trainer.calc_am_score(corpus, corpus_ali));
     } catch (std::exception const& e) {
       printf("error %s\n", e.what());
       return 2;

@@ -326,3 +326,23 @@ def test_cfg5_model_size(tmp_path, oracle_lib):
         assert np.array_equal(wa, wb) and np.array_equal(oa, ob) and len(wa) > 0
         corpus.close()
         lexh.close()
+
+
+def test_path_scores_are_calc_am_score_summands(tmp_path, oracle_lib):
+    """sr_path_scores_corpus: MixtureModel::score along an alignment (Trainer::calc_am_score, Training.cpp:605)."""
+    lex, spec, mp = _random_setup(tmp_path, 501, 30, 3, 2, (1, 5), 39)
+    feats, off = synth.make_batch(7, 20, 50, 39, seed=502)
+    o = oracle_lib.Oracle(mp, 39, lex)
+    rng = np.random.default_rng(503)
+    states = rng.integers(0, lex.n_states, size=len(feats)).astype(np.uint16)
+    dense = o.score_matrix(feats)
+    want = dense[np.arange(len(feats)), states]
+    with capi.Model.from_mixset(mp, 39) as m:
+        corpus = m.upload(feats, off)
+        got = corpus.path_scores(states, capi.GMM_EXACT)
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+        _assert_scores_close(corpus.path_scores(states, capi.GMM_MFMA), want)
+        with pytest.raises(capi.SrError):
+            corpus.path_scores(np.full(len(feats), lex.n_states, dtype=np.uint16))
+        corpus.close()
+    o.close()

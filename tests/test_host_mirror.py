@@ -102,4 +102,23 @@ def test_recognizer_and_aligner_mirror_on_gpu(driver, tmp_path, oracle_lib, kern
     st, cost = o.align_pruned(utts[0], np.asarray(aut, np.uint16), 30.0)
     al = [l for l in out if l.startswith("alignp")][0].split()
     assert [int(x) for x in al[2:]] == list(st) and abs(float(al[1]) - cost) <= 1e-9 * abs(cost)
+    # Trainer mirror: re-alignment of every utterance against its transcription, then calc_am_score
+    costs = [float(x) for x in [l for l in out if l.startswith("realign ")][0].split()[1:]]
+    states = [int(x) for x in [l for l in out if l.startswith("realign_states")][0].split()[1:]]
+    am = float([l for l in out if l.startswith("amscore")][0].split()[1])
+    k, total = 0, 0.0
+    for f, r, c in zip(utts, refs, costs):
+        a = [sil]
+        for w in r:
+            a += list(automaton[word_off[w]:word_off[w + 1]]) + [sil]
+        st, cost = o.align_pruned(f, np.asarray(a, np.uint16), 40.0)
+        assert states[k:k + len(f)] == list(st) and abs(c - cost) <= 1e-9 * abs(cost)
+        dense = o.score_matrix(f)
+        for t in range(len(f)):
+            total += dense[t, st[t]]
+        k += len(f)
+    if kernel == 1:
+        assert am == total / k
+    else:
+        assert abs(am - total / k) <= 1e-9 * abs(am)
     o.close()
