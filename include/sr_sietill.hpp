@@ -11,6 +11,8 @@
 //   sr::Corpus                 Corpus (feature store)       sietill/Corpus.hpp:55-84
 //   sr::Recognizer             Recognizer                   sietill/Recognizer.hpp:91-132
 //   sr::Aligner                Aligner                      sietill/Alignment.hpp:19-63
+//   sr::FeaturePostProcessor   SignalAnalysis::process_features  sietill/SignalAnalysis.cpp:320-336,340-349,379-399
+//   sr::read_feature_file, write_alignment, read_alignment    sietill/IO.cpp:48-69, Alignment.cpp:303-318
 //   sr::Trainer (re-alignment) Trainer::train's align loop   sietill/Training.cpp:163-184, :239-253, :585-612
 //
 // Differences, all forced by the device boundary: features are passed as (pointer, frame count)
@@ -21,6 +23,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <fstream>
 #include <limits>
 #include <stdexcept>
 #include <time.h>
@@ -352,6 +355,82 @@ class Aligner {
   MixtureModel& mixtures_;
   TdpModel tdp_;
 };
+
+// ---- on-disk formats either side of the path ------------------------------------------
+// `<feature-path><name>.mm2`: raw little-endian float32, n-features-file values per frame (IO.cpp:48-69)
+inline std::vector<float> read_feature_file(std::string const& path) {
+  std::vector<float> features;
+  std::ifstream in(path.c_str(), std::ios_base::in | std::ios_base::binary);
+  if (!in.good()) return features;  // the reference prints an error and returns an empty vector (IO.cpp:52-55)
+  in.seekg(0, std::ios_base::end);
+  const std::streamoff bytes = in.tellg();
+  in.seekg(0);
+  features.resize((size_t)bytes / sizeof(float));
+  in.read(reinterpret_cast<char*>(features.data()), features.size() * sizeof(float));
+  return features;
+}
+
+// What Corpus::read applies to every utterance (Corpus.cpp:101-102): static features -> static | delta | delta-delta,
+// optional mean/variance normalisation (computed in double, stored as float) and per-utterance maximum
+// normalisation of component 0 (SignalAnalysis.cpp:379-399, :320-336, :340-349).
+struct FeaturePostProcessor {
+  size_t n_features_in_file = 12, n_features_first = 12, n_features_second = 1, deriv_step = 3;  // SignalAnalysis.cpp:53-56
+  bool energy_max_norm = true;                                                                   // :46
+  std::vector<double> mean, stddev;  // empty: no mean/variance normalisation
+  size_t n_features_total() const { return n_features_in_file + n_features_first + n_features_second; }
+
+  // normalisation file: n_features_total f64 means then as many f64 standard deviations (SignalAnalysis.cpp:364-375)
+  bool read_normalization_file(std::string const& path) {
+    std::ifstream in(path.c_str(), std::ios_base::in | std::ios_base::binary);
+    if (!in.good()) return false;
+    mean.resize(n_features_total());
+    stddev.resize(n_features_total());
+    in.read(reinterpret_cast<char*>(mean.data()), sizeof(double) * mean.size());
+    in.read(reinterpret_cast<char*>(stddev.data()), sizeof(double) * stddev.size());
+    return (bool)in;
+  }
+
+  void process_features(std::vector<float>& features) const {
+    const size_t nf = n_features_in_file, nt = n_features_total(), T = features.size() / nf;
+    std::vector<float> seq(T * nt, 0.0f);
+    for (size_t f = 0; f < T; f++) std::copy(features.begin() + f * nf, features.begin() + (f + 1) * nf, seq.begin() + f * nt);
+    for (size_t t = 0; t < T; t++) {  // first derivative, window clamped at the start (:322-328)
+      const size_t a = std::max(t, deriv_step);
+      for (size_t k = 0; k < n_features_first; k++) seq[t * nt + nf + k] = seq[a * nt + k] - seq[(a - deriv_step) * nt + k];
+    }
+    for (size_t t = 0; t < T; t++) {  // second derivative from the first, window clamped at the end (:329-335)
+      const size_t a = std::min(t, T - 1 - deriv_step) + deriv_step;
+      for (size_t k = 0; k < n_features_second; k++) seq[t * nt + nf + n_features_first + k] = seq[a * nt + nf + k] - seq[t * nt + nf + k];
+    }
+    if (!mean.empty()) {
+      for (size_t t = 0; t < T; t++) {
+        for (size_t k = 0; k < nt; k++) seq[t * nt + k] = (float)((double)seq[t * nt + k] - mean[k]);
+        for (size_t k = 0; k < nt; k++) seq[t * nt + k] = (float)((double)seq[t * nt + k] / stddev[k]);
+      }
+    }
+    if (energy_max_norm) {
+      float mx = -std::numeric_limits<float>::infinity();
+      for (size_t t = 0; t < T; t++) mx = std::max(mx, seq[t * nt]);
+      for (size_t t = 0; t < T; t++) seq[t * nt] -= mx;
+    }
+    features.swap(seq);
+  }
+};
+
+// alignment dump: size_t max_aligns; size_t num_frames; AlignmentItem[num_frames * max_aligns] (Alignment.cpp:303-318)
+inline void write_alignment(std::ostream& out, std::vector<AlignmentItem> const& alignment, size_t max_aligns) {
+  const size_t num_frames = alignment.size() / max_aligns;
+  out.write(reinterpret_cast<const char*>(&max_aligns), sizeof max_aligns);
+  out.write(reinterpret_cast<const char*>(&num_frames), sizeof num_frames);
+  out.write(reinterpret_cast<const char*>(alignment.data()), max_aligns * num_frames * sizeof(AlignmentItem));
+}
+inline void read_alignment(std::istream& in, std::vector<AlignmentItem>& alignment, size_t& max_aligns) {
+  size_t num_frames = 0;
+  in.read(reinterpret_cast<char*>(&max_aligns), sizeof max_aligns);
+  in.read(reinterpret_cast<char*>(&num_frames), sizeof num_frames);
+  alignment.resize(num_frames * max_aligns);
+  in.read(reinterpret_cast<char*>(alignment.data()), max_aligns * num_frames * sizeof(AlignmentItem));
+}
 
 // ---- the training-side callers of the path (Training.hpp:18-107): NOT the EM trainer, only the two loops of
 // Trainer::train that run the scorer and the aligner over the whole corpus -- re-alignment (Training.cpp:163-184)

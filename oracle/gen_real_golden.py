@@ -114,7 +114,12 @@ def main():
 
     out = dict(dim=dim, feats=feats_cat, frame_off=np.asarray(frame_off, dtype=np.uint64),
                ref_flat=np.concatenate(refs), ref_off=np.cumsum([0] + [len(r) for r in refs]).astype(np.uint32),
-               names=np.asarray([t["name"] for t in test]), tdp=np.asarray(TDP))
+               names=np.asarray([t["name"] for t in test]), tdp=np.asarray(TDP),
+               # raw on-disk data for the format helpers of include/sr_sietill.hpp: two .mm2 files (raw float32,
+               # 12 per frame, IO.cpp:48-69) and the normalisation file (25 f64 means + 25 f64 std-devs, IO.hpp:20-28)
+               raw_mm2_0=np.fromfile(FEATS + test[0]["name"] + ".mm2", dtype="<f4"),
+               raw_mm2_1=np.fromfile(FEATS + test[1]["name"] + ".mm2", dtype="<f4"),
+               normalization=np.fromfile(os.path.join(REF, "Normalization.bin"), dtype="<f8"))
     for pname, (mix_path, pool) in models.items():
         out[f"model_{pname}"] = np.frombuffer(open(mix_path, "rb").read(), dtype=np.uint8)
         for tag, beam, wp, athr in (("wide", 200.0, 80.0, 120.0), ("tight", 40.0, 30.0, 25.0)):

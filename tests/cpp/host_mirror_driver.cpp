@@ -52,6 +52,25 @@ int main(int argc, char** argv) {
     printf("%g %g %g %g %g\n", tdp.score(0, 0), tdp.score(5, 0), tdp.score(5, 1), tdp.score(5, 2), tdp.score(5, 3));
     return 0;
   }
+  if (argc >= 5 && !strcmp(argv[1], "features")) {  // features <file.mm2> <normalization.bin|-> <out.f32>
+    std::vector<float> f = sr::read_feature_file(argv[2]);
+    sr::FeaturePostProcessor pp;
+    if (strcmp(argv[3], "-") && !pp.read_normalization_file(argv[3])) { printf("error normalization\n"); return 2; }
+    pp.process_features(f);
+    std::ofstream out(argv[4], std::ios::binary);
+    out.write(reinterpret_cast<const char*>(f.data()), sizeof(float) * f.size());
+    // alignment dump round trip through the reference's file format
+    std::vector<sr::AlignmentItem> ali(7), back;
+    for (size_t i = 0; i < ali.size(); i++) { ali[i].count = 1; ali[i].state = (uint16_t)(3 * i); ali[i].weight = 1.0f; }
+    { std::ofstream d(std::string(argv[4]) + ".dump", std::ios::binary); sr::write_alignment(d, ali, 1); }
+    size_t ma = 0;
+    { std::ifstream d(std::string(argv[4]) + ".dump", std::ios::binary); sr::read_alignment(d, back, ma); }
+    bool same = ma == 1 && back.size() == ali.size();
+    for (size_t i = 0; same && i < ali.size(); i++) same = back[i].state == ali[i].state && back[i].count == 1 && back[i].weight == 1.0f;
+    printf("%zu frames x %zu; dump %s, item %zu bytes\n", f.size() / pp.n_features_total(), pp.n_features_total(), same ? "ok" : "BAD",
+           sizeof(sr::AlignmentItem));
+    return 0;
+  }
   if (argc >= 5 && !strcmp(argv[1], "run")) {
     try {
       const size_t dim = std::stoul(argv[3]);

@@ -99,3 +99,32 @@ def test_gpu_matches_reference_on_real_speech(real, tmp_path, pname, kernel):
                 np.testing.assert_allclose(cost2, z[f"{key}_align_pruned_cost"], rtol=1e-6)
         corpus.close()
         lexh.close()
+
+
+def test_feature_post_processing_matches_reference_corpus_reader(real, tmp_path):
+    """sr::read_feature_file + sr::FeaturePostProcessor (include/sr_sietill.hpp) on the raw .mm2 bytes of two test
+    utterances must give, bit for bit, what the reference's Corpus::read -> SignalAnalysis::process_features produced
+    (delta / delta-delta, mean-variance and energy-maximum normalisation)."""
+    import subprocess
+
+    from tests.test_host_mirror import DRIVER
+    from speechrecognition_amd import build
+    build.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tests", "cpp", "host_mirror_driver.cpp")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(root, "include"), src, "-o", DRIVER,
+                           "-L" + os.path.join(root, "speechrecognition_amd"), "-lsrgpu",
+                           "-Wl,-rpath,$ORIGIN/../../speechrecognition_amd", "-Wl,-rpath,/opt/rocm/lib"])
+    z = real
+    norm = tmp_path / "Normalization.bin"
+    norm.write_bytes(z["normalization"].astype("<f8").tobytes())
+    off = z["frame_off"].astype(np.int64)
+    for i in (0, 1):
+        raw = tmp_path / f"u{i}.mm2"
+        raw.write_bytes(z[f"raw_mm2_{i}"].astype("<f4").tobytes())
+        outp = tmp_path / f"u{i}.f32"
+        msg = subprocess.check_output([DRIVER, "features", str(raw), str(norm), str(outp)], text=True)
+        assert "dump ok, item 8 bytes" in msg  # AlignmentItem is 8 bytes like the reference's (Types.hpp:29-38)
+        got = np.fromfile(outp, dtype="<f4").reshape(-1, 25)
+        want = z["feats"][off[i]:off[i + 1]]
+        assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
