@@ -168,6 +168,36 @@ def main():
               model_seed=[lex.n_states, 8, 39, 23], score_sample=4096, align_words=[17, 250, 99, 4],
               note="model = synth.make_mixset(1000, 8, 39, seed=23)")
 
+    # EM accumulation (MixtureModel::accumulate, Mixtures.cpp:278-372): the reference's accumulators, read back from
+    # what MixtureModel::write stores, for a random state path in the three modes (max-approx, first pass, soft)
+    lex = synth.make_lexicon(6, 3, 1)
+    rng = np.random.default_rng(41)
+    spec = synth.make_mixset(lex.n_states, rng.integers(1, 5, size=lex.n_states), 39, seed=41, tie_vars=True)
+    tmp = tempfile.mkdtemp()
+    mp, cp = os.path.join(tmp, "m.mix"), os.path.join(tmp, "c.json")
+    synth.write_mixset(mp, spec)
+    synth.write_config(cp, mp)
+    feats = synth.make_features(500, 39, 42)
+    states = rng.integers(0, lex.n_states, size=500).astype(np.uint16)
+    d = dict(lex_word_states=lex.word_states, lex_word_reps=lex.word_reps, lex_silence=lex.silence_idx, feats=feats,
+             states=states, var_keep=np.unique(spec.dens_var))
+    d.update({"model_" + k: v for k, v in spec_arrays(spec).items()})
+    for tag, fp, ma in (("max", False, True), ("first", True, True), ("soft", False, False)):
+        ref = po.Reference(cp, 39, lex, max_approx=ma)
+        orc = po.Oracle(mp, 39, lex, max_approx=ma)
+        outp = os.path.join(tmp, f"acc_{tag}.mix")
+        ref.accumulate_and_write(feats, states, outp, first_pass=fp, max_approx=ma)
+        got = synth.read_mixset(outp)
+        a, w, v, vw = orc.accumulate(feats, states, first_pass=fp, max_approx=ma)
+        keep = d["var_keep"]
+        assert np.array_equal(got.mean_acc, a) and np.array_equal(got.mean_w, w)
+        assert np.array_equal(got.var_acc, v[keep]) and np.array_equal(got.var_w, vw[keep])
+        d.update({f"{tag}_mean_acc": got.mean_acc, f"{tag}_mean_w": got.mean_w, f"{tag}_var_acc": got.var_acc,
+                  f"{tag}_var_w": got.var_w})
+        ref.close(); orc.close()
+    np.savez_compressed(os.path.join(OUT, "accumulate.npz"), **d)
+    print("accumulate: 3 modes, 500 frames")
+
     # edit distance known answers (Recognizer.cpp:332-389, including its row-0 insertion quirk)
     lex = synth.make_lexicon(1, 3, 1)
     tmp = tempfile.mkdtemp()

@@ -89,6 +89,7 @@ def _lib():
         C.c_double, _u16p,
     ]
     L.orc_edit_distance.argtypes = [_u64p, C.c_size_t, _u64p, C.c_size_t, _u16p]
+    L.orc_accumulate.argtypes = [C.c_void_p, _f32p, C.c_size_t, _u16p, C.c_int, C.c_int, _f64p, _f64p, _f64p, _f64p]
     L.orc_recognize_batch.restype = C.c_double
     L.orc_recognize_batch.argtypes = [
         C.c_void_p, C.POINTER(_Lex), C.POINTER(_Tdp), C.POINTER(_Search), _f32p, _u64p, C.c_size_t, C.c_uint32,
@@ -209,6 +210,16 @@ class Oracle:
                                        self.dim, float(threshold), out)
         return out, cost
 
+    def accumulate(self, feats, states, first_pass=False, max_approx=True):
+        """-> (mean_acc [n_mean, D], mean_w [n_mean], var_acc [n_var, D], var_w [n_var])"""
+        feats = np.ascontiguousarray(feats, dtype=np.float32)
+        states = np.ascontiguousarray(states, dtype=np.uint16)
+        nm, nv, D = self.L.orc_model_num_means(self.h), self.L.orc_model_num_vars(self.h), self.dim
+        ma, mw = np.zeros((nm, D)), np.zeros(nm)
+        va, vw = np.zeros((nv, D)), np.zeros(nv)
+        self.L.orc_accumulate(self.h, feats, feats.shape[0], states, int(first_pass), int(max_approx), ma, mw, va, vw)
+        return ma, mw, va, vw
+
     def edit_distance(self, ref, hyp):
         out = np.zeros(4, dtype=np.uint16)
         self.L.orc_edit_distance(np.ascontiguousarray(ref, dtype=np.uint64), len(ref),
@@ -251,6 +262,7 @@ class Reference:
         L.ref_align_full.argtypes = [C.c_void_p, _f32p, C.c_size_t, _u16p, C.c_size_t, _u16p]
         L.ref_align_pruned.restype = C.c_double
         L.ref_align_pruned.argtypes = [C.c_void_p, _f32p, C.c_size_t, _u16p, C.c_size_t, C.c_double, _u16p]
+        L.ref_accumulate_and_write.argtypes = [C.c_void_p, _f32p, C.c_size_t, _u16p, C.c_int, C.c_int, C.c_char_p]
         self.dim = dim
         self.h = L.ref_create(str(config_path).encode(), dim, lex.n_words,
                               np.ascontiguousarray(lex.word_states, dtype=np.uint16),
@@ -293,6 +305,12 @@ class Reference:
         out = np.zeros(feats.shape[0], dtype=np.uint16)
         cost = self.L.ref_align_full(self.h, feats, feats.shape[0], ref, len(ref), out)
         return out, cost
+
+    def accumulate_and_write(self, feats, states, out_path, first_pass=False, max_approx=True):
+        feats = np.ascontiguousarray(feats, dtype=np.float32)
+        states = np.ascontiguousarray(states, dtype=np.uint16)
+        self.L.ref_accumulate_and_write(self.h, feats, feats.shape[0], states, int(first_pass), int(max_approx),
+                                        str(out_path).encode())
 
     def align_pruned(self, feats, ref, threshold):
         feats = np.ascontiguousarray(feats, dtype=np.float32)

@@ -144,6 +144,21 @@ double ref_align_pruned(void* h, const float* feats, size_t T, const uint16_t* r
   return run_align(static_cast<RefCtx*>(h), feats, T, ref, N, 1, thr, out_states);
 }
 
+// MixtureModel::accumulate (Mixtures.cpp:278-372) on a state path, then MixtureModel::write (:834-878) to `out_path`:
+// the written MIXSET holds the accumulators (the reference keeps them private otherwise).
+void ref_accumulate_and_write(void* h, const float* feats, size_t T, const uint16_t* states, int first_pass, int max_approx,
+                              const char* out_path) {
+  RefCtx* c = static_cast<RefCtx*>(h);
+  std::vector<float> buf = padded(feats, T, c->dim);
+  Alignment alignment(T);
+  for (size_t t = 0; t < T; t++) alignment[t] = AlignmentItem(1, states[t], 1.0f);
+  c->mixtures->accumulate(ConstAlignmentIter(&alignment[0], 1), ConstAlignmentIter(&alignment[0] + T, 1),
+                          FeatureIter(buf.data(), c->dim), FeatureIter(buf.data() + T * c->dim, c->dim), first_pass != 0,
+                          max_approx != 0);
+  std::ofstream out(out_path, std::ios_base::out | std::ios_base::trunc | std::ios_base::binary);
+  c->mixtures->write(out);
+}
+
 // ---- real-data helpers (oracle/gen_real_golden.py): the reference's own corpus reader, front-end
 // post-processing (Corpus::read -> SignalAnalysis::process_features, Corpus.cpp:89-111) and GMM trainer
 // (Trainer::train, Training.cpp:44-235) on SieTill features from /root/reference/data/new_features.

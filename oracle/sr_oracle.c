@@ -226,6 +226,18 @@ static inline double density_score(const orc_model* m, const float* x, uint32_t 
   return score;
 }
 
+/* min_score (Mixtures.cpp:696-713) whatever the model's max_approx flag */
+static double orc_score_argmin_raw(const orc_model* m, const float* x, uint32_t state, uint32_t* density) {
+  const uint32_t b = m->mix_off[state], e = m->mix_off[state + 1];
+  double best = 1e10; uint32_t bi = 0;
+  for (uint32_t k = b; k < e; k++) {
+    double s = density_score(m, x, m->mix_mean[k], m->mix_var[k]);
+    if (s < best) { bi = k - b; best = s; }
+  }
+  if (density) *density = bi;
+  return best;
+}
+
 double orc_score_argmin(const orc_model* m, const float* x, uint32_t state, uint32_t* density) {
   const uint32_t b = m->mix_off[state], e = m->mix_off[state + 1];
   if (m->max_approx) { /* min_score, Mixtures.cpp:696-713: seed 1e10, idx 0, strict < */
@@ -254,6 +266,43 @@ void orc_score_matrix(const orc_model* m, const float* feats, size_t T, double* 
 #endif
   for (long t = 0; t < (long)T; t++)
     for (size_t s = 0; s < S; s++) out[(size_t)t * S + s] = orc_score(m, feats + (size_t)t * D, (uint32_t)s);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+void orc_accumulate(const orc_model* m, const float* feats, size_t T, const uint16_t* states, int first_pass,
+                    int max_approx, double* mean_acc, double* mean_w, double* var_acc, double* var_w) {
+  const uint32_t D = m->dim;
+  for (size_t i = 0; i < (size_t)m->n_mean * D; i++) mean_acc[i] = 0.0;   /* reset_accumulators, :235-247 */
+  for (size_t i = 0; i < m->n_mean; i++) mean_w[i] = 0.0;
+  for (size_t i = 0; i < (size_t)m->n_var * D; i++) var_acc[i] = 1e-4;    /* minimal_variance_value_, :167,243 */
+  for (size_t i = 0; i < m->n_var; i++) var_w[i] = 0.0;
+  double* p = (double*)malloc(sizeof(double) * (m->n_dens_total ? m->n_dens_total : 1));
+  for (size_t t = 0; t < T; t++) {
+    const float* x = feats + t * D;
+    const uint32_t s = states[t], b = m->mix_off[s], n = m->mix_off[s + 1] - b;
+    for (uint32_t d = 0; d < n; d++) p[d] = 0.0;
+    uint32_t arg = 0;
+    if (max_approx && !first_pass) (void)orc_score_argmin_raw(m, x, s, &arg);
+    for (uint32_t d = 0; d < n; d++) {
+      if (first_pass) p[0] = 1.0;
+      else if (max_approx && d == arg) p[d] = 1.0;
+      else if (!max_approx) p[d] = exp(-1 * density_score(m, x, m->mix_mean[b + d], m->mix_var[b + d]));
+    }
+    if (!max_approx) {
+      double sum = 0.0;
+      for (uint32_t d = 0; d < n; d++) sum += p[d];
+      for (uint32_t d = 0; d < n; d++) p[d] = p[d] / sum;
+    }
+    for (uint32_t d = 0; d < n; d++) {
+      if (p[d] < 1e-8) continue;
+      const uint32_t mi = m->mix_mean[b + d], vi = m->mix_var[b + d];
+      mean_w[mi] += p[d];
+      var_w[vi] += p[d];
+      for (uint32_t k = 0; k < D; k++) mean_acc[(size_t)mi * D + k] = mean_acc[(size_t)mi * D + k] + p[d] * x[k];
+      for (uint32_t k = 0; k < D; k++) var_acc[(size_t)vi * D + k] = var_acc[(size_t)vi * D + k] + p[d] * x[k] * x[k];
+    }
+  }
+  free(p);
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -109,6 +109,14 @@ double orc_align_pruned(const orc_model* m, const double* dense, size_t dense_st
  * row-0 insertion counter quirk). out4 = {total, substitutions, insertions, deletions}. */
 void orc_edit_distance(const uint64_t* ref, size_t n_ref, const uint64_t* hyp, size_t n_hyp, uint16_t out4[4]);
 
+/* MixtureModel::accumulate (Mixtures.cpp:278-372) after reset_accumulators (:235-247): EM statistics of a
+ * state path (`states[t]` = aligned mixture of frame t, one item per frame).  first_pass: every frame goes to
+ * density 0 of its mixture; else max_approx: to the arg-min density (min_score); else soft memberships
+ * exp(-score)/sum with entries below 1e-8 skipped.  Outputs are indexed like the model's mean / variance
+ * tables: mean_acc[n_mean*D], mean_w[n_mean], var_acc[n_var*D] (starts at 1e-4, :243), var_w[n_var]. */
+void orc_accumulate(const orc_model* m, const float* feats, size_t T, const uint16_t* states, int first_pass,
+                    int max_approx, double* mean_acc, double* mean_w, double* var_acc, double* var_w);
+
 /* Corpus-level loop like Recognizer::recognize (Recognizer.cpp:38-92): decodes utterances
  * [0,n_utts) with `n_threads` OpenMP threads (schedule(dynamic), like :46); returns wall seconds
  * of the utterance loop (the reference's timed region, :45-80). frame_off[n_utts+1] in frames.

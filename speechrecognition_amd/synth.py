@@ -196,3 +196,33 @@ def write_config(path, mixset_path, tdp=(3.0, 0.0, 30.0), am_threshold=200.0, wo
     with open(path, "w") as f:
         json.dump(cfg, f)
     return cfg
+
+
+def read_mixset(path) -> MixsetSpec:
+    """Parse a MIXSET v2 file back into accumulators + topology (inverse of write_mixset)."""
+    buf = open(path, "rb").read()
+    assert buf[:8] == MAGIC
+    version, D = struct.unpack_from("<II", buf, 8)
+    assert version == 2
+    pos = 16
+    blocks = []
+    for _ in range(2):
+        (n,) = struct.unpack_from("<I", buf, pos)
+        pos += 4
+        rec = np.frombuffer(buf, dtype=np.dtype([("dim", "<u4"), ("acc", "<f8", (D,)), ("w", "<f8")]), count=n, offset=pos)
+        pos += rec.nbytes
+        blocks.append((rec["acc"].copy().reshape(n, D), rec["w"].copy()))
+    (n_dens,) = struct.unpack_from("<I", buf, pos)
+    pos += 4
+    dens = np.frombuffer(buf, dtype="<u4", count=2 * n_dens, offset=pos).reshape(n_dens, 2)
+    pos += 8 * n_dens
+    (n_mix,) = struct.unpack_from("<I", buf, pos)
+    pos += 4
+    mixtures = []
+    for _ in range(n_mix):
+        (nd,) = struct.unpack_from("<I", buf, pos)
+        pos += 4
+        rec = np.frombuffer(buf, dtype=np.dtype([("idx", "<u4"), ("w", "<f8")]), count=nd, offset=pos)
+        pos += rec.nbytes
+        mixtures.append([int(x) for x in rec["idx"]])
+    return MixsetSpec(D, blocks[0][0], blocks[0][1], blocks[1][0], blocks[1][1], dens[:, 0].copy(), dens[:, 1].copy(), mixtures)

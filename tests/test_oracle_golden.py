@@ -104,3 +104,26 @@ def test_oracle_vs_compiled_reference_random(seed, oracle_lib, tmp_path):
     assert np.array_equal(a[0], b[0]) and a[1] == b[1]
     ref.close()
     orc.close()
+
+
+def _accumulate_case(tmp_path):
+    from speechrecognition_amd import synth as sy
+    z = np.load(os.path.join(GOLDEN, "accumulate.npz"))
+    lex = sy.LexiconSpec(z["lex_word_states"], z["lex_word_reps"], int(z["lex_silence"]))
+    mixtures = [list(z["model_mix_dens"][z["model_mix_off"][s]:z["model_mix_off"][s + 1]]) for s in range(len(z["model_mix_off"]) - 1)]
+    spec = sy.MixsetSpec(int(z["model_dim"]), z["model_mean_acc"], z["model_mean_w"], z["model_var_acc"], z["model_var_w"],
+                         z["model_dens_mean"], z["model_dens_var"], mixtures)
+    mp = str(tmp_path / "acc.mix")
+    sy.write_mixset(mp, spec)
+    return z, lex, spec, mp
+
+
+@pytest.mark.parametrize("tag,first_pass,max_approx", [("max", False, True), ("first", True, True), ("soft", False, False)])
+def test_oracle_accumulate_matches_reference_golden(tag, first_pass, max_approx, oracle_lib, tmp_path):
+    z, lex, spec, mp = _accumulate_case(tmp_path)
+    o = oracle_lib.Oracle(mp, 39, lex, max_approx=max_approx)
+    a, w, v, vw = o.accumulate(z["feats"], z["states"], first_pass=first_pass, max_approx=max_approx)
+    keep = z["var_keep"]  # MixtureModel::write drops unreferenced variances (Mixtures.cpp:131-144)
+    assert np.array_equal(a.view(np.uint64), z[f"{tag}_mean_acc"].view(np.uint64)) and np.array_equal(w, z[f"{tag}_mean_w"])
+    assert np.array_equal(v[keep].view(np.uint64), z[f"{tag}_var_acc"].view(np.uint64)) and np.array_equal(vw[keep], z[f"{tag}_var_w"])
+    o.close()
