@@ -137,6 +137,19 @@ SR_API int sr_align_corpus_pruned(sr_model* m, sr_corpus* c, const uint16_t* aut
  * sum of out[] divided by the frame count; the sum is left to the host so that it keeps the reference's order. */
 SR_API int sr_path_scores_corpus(sr_model* m, sr_corpus* c, const uint16_t* states, int gmm_kernel, double* out);
 
+/* ---- EM statistics: MixtureModel::accumulate (Mixtures.cpp:278-372) after reset_accumulators (:235-247) --------
+ * Tying: accumulator row of every density (mixture order), as MixtureDensity{mean_idx, var_idx} (Types.hpp:19-27).
+ * sr_model_load_mixset installs the file's own; models from sr_model_create default to one row per density. */
+SR_API int sr_model_set_tying(sr_model* m, uint32_t n_mean, uint32_t n_var, const uint32_t* dens_mean, const uint32_t* dens_var);
+SR_API int sr_model_tying_info(const sr_model* m, uint32_t* n_mean, uint32_t* n_var);
+/* states[total_frames]: aligned mixture per frame (an alignment from sr_align_corpus*).  first_pass: density 0 of
+ * the mixture gets every frame; else max_approx: the arg-min density; else soft memberships.  Outputs (host):
+ * mean_acc[n_mean*dim], mean_w[n_mean], var_acc[n_var*dim] (starts at 1e-4 like the reference), var_w[n_var].
+ * Rows are summed in frame order, so max-approx / first-pass results are bit-identical to the reference's; with
+ * several GPUs every rank accumulates its shard and the four arrays are all-reduced (sum) by the caller. */
+SR_API int sr_accumulate_corpus(sr_model* m, sr_corpus* c, const uint16_t* states, int first_pass, int max_approx,
+                                double* mean_acc, double* mean_w, double* var_acc, double* var_w);
+
 /* ---- measurement --------------------------------------------------------------------------------
  * When enabled, every kernel launch of this model handle is bracketed by HIP events on the
  * launch stream; sr_profile_read() synchronises and returns accumulated device times. */

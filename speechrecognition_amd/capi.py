@@ -21,7 +21,7 @@ POOL_GLOBAL, POOL_MIXTURE, POOL_NONE = 0, 1, 2
 SYMBOLS = [
     "sr_last_error", "sr_device_count", "sr_model_create", "sr_model_load_mixset", "sr_model_destroy", "sr_model_info",
     "sr_corpus_upload", "sr_corpus_destroy", "sr_score_corpus", "sr_score_frames", "sr_lexicon_create",
-    "sr_lexicon_destroy", "sr_recognize_corpus", "sr_recognize_batch", "sr_align_corpus", "sr_align_corpus_pruned", "sr_path_scores_corpus",
+    "sr_lexicon_destroy", "sr_recognize_corpus", "sr_recognize_batch", "sr_align_corpus", "sr_align_corpus_pruned", "sr_path_scores_corpus", "sr_model_set_tying", "sr_model_tying_info", "sr_accumulate_corpus",
     "sr_profile_enable", "sr_profile_reset", "sr_profile_read",
 ]
 
@@ -70,6 +70,9 @@ def lib():
         L.sr_align_corpus.argtypes = [vp, vp, vp, vp, C.POINTER(dbl * 3), C.c_uint16, i32, vp, vp]
         L.sr_align_corpus_pruned.argtypes = [vp, vp, vp, vp, C.POINTER(dbl * 3), C.c_uint16, dbl, i32, vp, vp]
         L.sr_path_scores_corpus.argtypes = [vp, vp, vp, i32, vp]
+        L.sr_model_set_tying.argtypes = [vp, u32, u32, vp, vp]
+        L.sr_model_tying_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
+        L.sr_accumulate_corpus.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp]
         L.sr_profile_enable.argtypes = [vp, i32]
         L.sr_profile_reset.argtypes = [vp]
         L.sr_profile_read.argtypes = [vp, C.POINTER(Profile)]
@@ -210,6 +213,18 @@ class Corpus:
             _check(lib().sr_align_corpus_pruned(self.model.h, self.h, _ptr(flat), _ptr(off), C.byref(t3), silence_state,
                                                 float(pruning_threshold), kernel, _ptr(states), _ptr(cost)))
         return states[: self.n_frames], cost[: self.n_utts]
+
+    def accumulate(self, states, first_pass=False, max_approx=True):
+        """EM statistics of an alignment (MixtureModel::accumulate) -> (mean_acc, mean_w, var_acc, var_w)."""
+        states = np.ascontiguousarray(states, dtype=np.uint16)
+        nm, nv = C.c_uint32(), C.c_uint32()
+        _check(lib().sr_model_tying_info(self.model.h, C.byref(nm), C.byref(nv)))
+        D = self.model.dim
+        ma, mw = np.zeros((nm.value, D)), np.zeros(nm.value)
+        va, vw = np.zeros((nv.value, D)), np.zeros(nv.value)
+        _check(lib().sr_accumulate_corpus(self.model.h, self.h, _ptr(states), int(first_pass), int(max_approx), _ptr(ma), _ptr(mw),
+                                          _ptr(va), _ptr(vw)))
+        return ma, mw, va, vw
 
     def path_scores(self, states, kernel=GMM_MFMA):
         """Emission cost along a state path (one state per frame): Trainer::calc_am_score's summands."""

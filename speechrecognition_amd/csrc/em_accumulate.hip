@@ -1,0 +1,150 @@
+// em_accumulate.hip -- EM statistics of an alignment on the GPU: MixtureModel::accumulate
+// (sietill/Mixtures.cpp:278-372) after reset_accumulators (:235-247).  The step on the far side of the aligner
+// in Trainer::train (Training.cpp:142-151,198-202).
+//
+// The reference adds frame after frame into per-density double accumulators; floating-point addition is not
+// associative, so to stay BIT-IDENTICAL in the max-approx and first-pass modes the frames of every
+// accumulator row are summed sequentially in frame order here too:
+//   1. em_assign_kernel   one thread per frame: (frame, density, weight) "pairs" -- the arg-min density of the
+//                         aligned mixture (min_score, :696-713, replaying density_score_sse's operation order),
+//                         density 0 on the first pass, or every density with its membership exp(-score)/sum
+//                         in soft mode (entries below 1e-8 are dropped like :334-336);
+//   2. a STABLE radix sort of the pairs by mean index (and again by variance index: tied variances are summed
+//      across the densities sharing them, in frame order);
+//   3. em_sum_kernel      one wave per accumulator row walks its pairs in order, lanes = feature dimensions:
+//                         mean_acc += w*x, var_acc += (w*x)*x (starting at 1e-4, :243), weight += w.
+// Parallelism is across rows (10^5 of them), never inside a row.  Soft mode uses the device exp, so its
+// weights differ from glibc's by an ulp or two: tolerance 1e-12 there, bit-exact otherwise.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace srgpu {
+
+#pragma clang fp contract(off)
+
+static constexpr int kAssignThreads = 128;
+
+__device__ inline double em_density_score(const float* x, const double* mu, const double* iv, double norm, double logw,
+                                          uint32_t D) {
+  double l0 = 0.0, l1 = 0.0;
+  const uint32_t D2 = D - (D & 1u);
+  for (uint32_t d = 0; d < D2; d += 2) {  // Mixtures.cpp:651-667: two partial sums (the SSE lanes)
+    double p = (double)x[d] - mu[d];
+    p = p * p;
+    p = p * iv[d];
+    l0 = l0 + p;
+    double q = (double)x[d + 1] - mu[d + 1];
+    q = q * q;
+    q = q * iv[d + 1];
+    l1 = l1 + q;
+  }
+  double dist = l0 + l1;
+  if (D & 1u) {
+    const double t = (double)x[D - 1] - mu[D - 1];
+    dist += t * t * iv[D - 1];
+  }
+  double score = norm + dist / 2;
+  score -= logw;
+  return score;
+}
+
+__global__ __launch_bounds__(kAssignThreads) void em_assign_kernel(EmArgs a) {
+  const uint64_t t = (uint64_t)blockIdx.x * kAssignThreads + threadIdx.x;
+  if (t >= a.n_frames) return;
+  const uint32_t D = a.dim;
+  const float* x = a.feats + t * D;
+  const uint32_t s = a.states[t], c0 = a.dens_off[s], c1 = a.dens_off[s + 1];
+  const uint64_t p0 = a.pair_off[t];  // first pair of this frame; one pair per density in soft mode, else one
+  if (a.first_pass || a.max_approx) {
+    uint32_t arg = c0;
+    if (!a.first_pass) {
+      double best = 1e10;  // min_score: seed 1e10, index 0, strict <
+      for (uint32_t c = c0; c < c1; c++) {
+        const double sc = em_density_score(x, a.means + (uint64_t)c * D, a.inv_vars + (uint64_t)c * D, a.norm[c], a.logw[c], D);
+        if (sc < best) { best = sc; arg = c; }
+      }
+    }
+    const bool any = c1 > c0;  // an empty mixture contributes nothing
+    a.pair_frame[p0] = (uint32_t)t;
+    a.pair_w[p0] = 1.0;
+    a.key_mean[p0] = any ? a.dens_mean[arg] : 0xFFFFFFFFu;
+    a.key_var[p0] = any ? a.dens_var[arg] : 0xFFFFFFFFu;
+    return;
+  }
+  double sum = 0.0;  // soft memberships: std::accumulate from 0.0 in density order (:320-321)
+  for (uint32_t c = c0; c < c1; c++) {
+    const double p = exp(-1 * em_density_score(x, a.means + (uint64_t)c * D, a.inv_vars + (uint64_t)c * D, a.norm[c], a.logw[c], D));
+    a.pair_w[p0 + (c - c0)] = p;
+    sum += p;
+  }
+  for (uint32_t c = c0; c < c1; c++) {
+    const uint64_t i = p0 + (c - c0);
+    const double p = a.pair_w[i] / sum;
+    const bool keep = !(p < 1e-8);  // :334-336
+    a.pair_frame[i] = (uint32_t)t;
+    a.pair_w[i] = p;
+    a.key_mean[i] = keep ? a.dens_mean[c] : 0xFFFFFFFFu;
+    a.key_var[i] = keep ? a.dens_var[c] : 0xFFFFFFFFu;
+  }
+}
+
+// one wave per accumulator row; SQUARE: variance statistics
+template <bool SQUARE>
+__global__ __launch_bounds__(64) void em_sum_kernel(EmArgs a, const uint32_t* sorted_keys, const uint32_t* sorted_pairs,
+                                                    uint32_t n_rows, double* acc, double* weight) {
+  const uint32_t row = blockIdx.x, lane = threadIdx.x;
+  if (row >= n_rows) return;
+  // [lo, hi) = pairs whose key is `row` (binary search; every lane does the same search)
+  uint64_t lo = 0, hi = a.n_pairs;
+  while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (sorted_keys[mid] < row) lo = mid + 1; else hi = mid; }
+  uint64_t e = lo, hi2 = a.n_pairs;
+  while (e < hi2) { const uint64_t mid = (e + hi2) >> 1; if (sorted_keys[mid] <= row) e = mid + 1; else hi2 = mid; }
+  const uint32_t D = a.dim;
+  for (uint32_t d0 = 0; d0 < D; d0 += 64) {
+    const uint32_t d = d0 + lane;
+    double sum = SQUARE ? 1e-4 : 0.0;  // reset_accumulators: variances start at minimal_variance_value_ (:167,243)
+    double w = 0.0;
+    for (uint64_t i = lo; i < e; i++) {
+      const uint32_t pair = sorted_pairs[i];
+      const double p = a.pair_w[pair];
+      const float xv = d < D ? a.feats[(uint64_t)a.pair_frame[pair] * D + d] : 0.0f;
+      const double y = (double)xv;
+      if (SQUARE) sum = sum + p * y * y;  // scale_add_square: x + scale * y * y  (:56-64)
+      else sum = sum + p * y;             // scale_add:        x + scale * y      (:46-54)
+      w += p;
+    }
+    if (d < D) acc[(uint64_t)row * D + d] = sum;
+    if (d0 == 0 && lane == 0) weight[row] = w;
+  }
+}
+
+size_t em_sort_temp_bytes(uint64_t n_pairs) {
+  size_t bytes = 0;
+  (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+                                           (uint32_t*)nullptr, (int)n_pairs);
+  return bytes;
+}
+
+hipError_t launch_em_accumulate(const EmArgs& a, void* sort_temp, size_t sort_temp_bytes, uint32_t* iota, uint32_t* keys_sorted,
+                                uint32_t* pairs_sorted, double* mean_acc, double* mean_w, double* var_acc, double* var_w,
+                                hipStream_t stream) {
+  if (a.n_frames == 0 || a.n_pairs == 0) return hipSuccess;
+  hipLaunchKernelGGL(em_assign_kernel, dim3((unsigned)((a.n_frames + kAssignThreads - 1) / kAssignThreads)), dim3(kAssignThreads), 0,
+                     stream, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  // LSD radix sort is stable: pairs of one row stay in generation (= frame, then density) order
+  e = hipcub::DeviceRadixSort::SortPairs(sort_temp, sort_temp_bytes, a.key_mean, keys_sorted, iota, pairs_sorted, (int)a.n_pairs, 0, 32, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((em_sum_kernel<false>), dim3(a.n_mean), dim3(64), 0, stream, a, keys_sorted, pairs_sorted, a.n_mean, mean_acc, mean_w);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  e = hipcub::DeviceRadixSort::SortPairs(sort_temp, sort_temp_bytes, a.key_var, keys_sorted, iota, pairs_sorted, (int)a.n_pairs, 0, 32, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((em_sum_kernel<true>), dim3(a.n_var), dim3(64), 0, stream, a, keys_sorted, pairs_sorted, a.n_var, var_acc, var_w);
+  return hipGetLastError();
+}
+
+}  // namespace srgpu

@@ -15,6 +15,8 @@ struct MixsetTables {
   uint32_t dim = 0;
   std::vector<uint32_t> dens_off;
   std::vector<double> means, inv_vars, norm, logw;
+  std::vector<uint32_t> dens_mean, dens_var;  // accumulator rows (MixtureDensity{mean_idx, var_idx}) per density
+  uint32_t n_mean = 0, n_var = 0;
 };
 
 // returns nullptr on success or the reference's error text (sietill/Mixtures.cpp:753-825)

@@ -111,4 +111,23 @@ uint32_t align_max_positions();
 hipError_t launch_path_scores(const double* scores, uint32_t ld, uint64_t frame_base, uint64_t f0, uint64_t f1,
                               const uint16_t* states, double* out, hipStream_t stream);
 
+// ---- EM accumulation (em_accumulate.hip) ------------------------------------------------------------------------
+struct EmArgs {
+  const float* feats;
+  uint64_t n_frames, n_pairs;
+  uint32_t dim;
+  const uint16_t* states;      // [n_frames] aligned mixture per frame
+  const uint64_t* pair_off;    // [n_frames] first pair of each frame
+  const uint32_t* dens_off;    // model (per density, mixture order)
+  const double* means; const double* inv_vars; const double* norm; const double* logw;
+  const uint32_t* dens_mean; const uint32_t* dens_var;  // accumulator row of each density
+  uint32_t n_mean, n_var;
+  int first_pass, max_approx;
+  uint32_t* pair_frame; double* pair_w; uint32_t* key_mean; uint32_t* key_var;  // [n_pairs] workspace
+};
+size_t em_sort_temp_bytes(uint64_t n_pairs);
+hipError_t launch_em_accumulate(const EmArgs& a, void* sort_temp, size_t sort_temp_bytes, uint32_t* iota, uint32_t* keys_sorted,
+                                uint32_t* pairs_sorted, double* mean_acc, double* mean_w, double* var_acc, double* var_w,
+                                hipStream_t stream);
+
 }  // namespace srgpu

@@ -139,12 +139,16 @@ const char* load_mixset(const char* path, uint32_t dim, int pooling, MixsetTable
   out->dim = dim;
   out->dens_off.assign(1, 0u);
   out->means.clear(); out->inv_vars.clear(); out->norm.clear(); out->logw.clear();
+  out->dens_mean.clear(); out->dens_var.clear();
+  out->n_mean = mean_acc.n; out->n_var = var_acc.n;
   for (auto& mix : mixtures) {
     for (const Density& dn : mix) {
       out->means.insert(out->means.end(), &mean[dn.mean * D], &mean[dn.mean * D] + D);
       out->inv_vars.insert(out->inv_vars.end(), &ivar[dn.var * D], &ivar[dn.var * D] + D);
       out->norm.push_back(nrm[dn.var]);
       out->logw.push_back(logw[dn.mean]);
+      out->dens_mean.push_back(dn.mean);
+      out->dens_var.push_back(dn.var);
     }
     out->dens_off.push_back((uint32_t)out->norm.size());
   }
@@ -159,6 +163,11 @@ extern "C" SR_API int sr_model_load_mixset(const char* path, uint32_t dim, int p
   if (pooling < 0 || pooling > 2) return srhost::set_error(SR_EINVAL, "pooling must be 0 (global), 1 (mixture) or 2 (none)");
   srhost::MixsetTables t;
   if (const char* e = srhost::load_mixset(path, dim, pooling, &t)) return srhost::set_error(SR_EINVAL, e);
-  return sr_model_create(device, dim, (uint32_t)t.dens_off.size() - 1, t.dens_off.data(), t.means.data(), t.inv_vars.data(),
-                         t.norm.data(), t.logw.data(), max_approx, out);
+  int rc = sr_model_create(device, dim, (uint32_t)t.dens_off.size() - 1, t.dens_off.data(), t.means.data(), t.inv_vars.data(),
+                           t.norm.data(), t.logw.data(), max_approx, out);
+  if (rc == SR_OK && !t.dens_mean.empty()) {
+    rc = sr_model_set_tying(*out, t.n_mean, t.n_var, t.dens_mean.data(), t.dens_var.data());
+    if (rc != SR_OK) { sr_model_destroy(*out); *out = nullptr; }
+  }
+  return rc;
 }

@@ -79,6 +79,10 @@ struct sr_model {
   // exact-kernel tables (finalised, per density)
   DevBuf<uint32_t> dens_off;
   DevBuf<double> means, inv_vars, norm, logw;
+  // EM tying (accumulator rows)
+  DevBuf<uint32_t> dens_mean, dens_var;
+  std::vector<uint32_t> h_dens_off;
+  uint32_t n_mean = 0, n_var = 0;
   // MFMA packing
   int ksteps = 0;
   uint32_t n_blocks = 0, n_groups = 0;
@@ -115,6 +119,11 @@ struct sr_corpus {
   DevBuf<uint64_t> aut_off, bp_off;
   DevBuf<uint8_t> backptr;
   DevBuf<double> out_cost, path_scores;
+  // EM accumulation workspace
+  DevBuf<uint64_t> pair_off;
+  DevBuf<uint32_t> pair_frame, key_mean, key_var, iota, keys_sorted, pairs_sorted;
+  DevBuf<double> pair_w, acc_mean, acc_var, w_mean, w_var;
+  DevBuf<unsigned char> sort_temp;
 };
 
 struct sr_lexicon {
@@ -368,6 +377,14 @@ int sr_model_create(int device, uint32_t dim, uint32_t n_states, const uint32_t*
       break;
     }
     rc = pack_model(m, dens_off, means, inv_vars, norm, logw);
+    if (rc == SR_OK) {
+      std::vector<uint32_t> ident(C);
+      std::iota(ident.begin(), ident.end(), 0u);
+      m->h_dens_off.assign(dens_off, dens_off + n_states + 1);
+      m->n_mean = m->n_var = (uint32_t)C;
+      if ((e = m->dens_mean.upload(ident.data(), C)) != hipSuccess || (e = m->dens_var.upload(ident.data(), C)) != hipSuccess)
+        rc = fail(SR_EHIP, "tying upload: %s", hipGetErrorString(e));
+    }
   } while (0);
   if (rc != SR_OK) { sr_model_destroy(m); return rc; }
   const char* env = getenv("SRGPU_SCORE_CHUNK_MB");
@@ -386,6 +403,7 @@ int sr_model_destroy(sr_model* m) {
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
   for (auto& ep : m->events) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+  m->dens_mean.release(); m->dens_var.release();
   m->dens_off.release(); m->means.release(); m->inv_vars.release(); m->norm.release(); m->logw.release();
   m->apack.release(); m->blk_meta.release(); m->grp_state.release(); m->split_begin.release();
   m->scores[0].release(); m->scores[1].release();
@@ -442,6 +460,9 @@ int sr_corpus_destroy(sr_corpus* c) {
   c->feats.release(); c->d_frame_off.release(); c->tb_score.release(); c->tb_word.release(); c->tb_bkp.release();
   c->out_words.release(); c->out_count.release(); c->out_flags.release(); c->automata.release(); c->out_states.release();
   c->aut_off.release(); c->bp_off.release(); c->backptr.release(); c->out_cost.release(); c->path_scores.release();
+  c->pair_off.release(); c->pair_frame.release(); c->key_mean.release(); c->key_var.release(); c->iota.release();
+  c->keys_sorted.release(); c->pairs_sorted.release(); c->pair_w.release(); c->acc_mean.release(); c->acc_var.release();
+  c->w_mean.release(); c->w_var.release(); c->sort_temp.release();
   delete c;
   return SR_OK;
 }
@@ -757,6 +778,82 @@ int sr_path_scores_corpus(sr_model* m, sr_corpus* c, const uint16_t* states, int
   HIP_TRY(hipStreamSynchronize(m->s_gmm));
   HIP_TRY(hipMemcpy(out, c->path_scores.p, sizeof(double) * F, hipMemcpyDeviceToHost));
   if (m->profiling) m->prof.frames += F;
+  return SR_OK;
+}
+
+int sr_model_set_tying(sr_model* m, uint32_t n_mean, uint32_t n_var, const uint32_t* dens_mean, const uint32_t* dens_var) {
+  int rc = check_model(m);
+  if (rc) return rc;
+  if (!dens_mean || !dens_var) return fail(SR_EINVAL, "null tying table");
+  for (uint64_t c = 0; c < m->n_dens; c++)
+    if (dens_mean[c] >= n_mean || dens_var[c] >= n_var) return fail(SR_EINVAL, "density %llu: tying index out of range", (unsigned long long)c);
+  HIP_TRY(m->dens_mean.upload(dens_mean, m->n_dens));
+  HIP_TRY(m->dens_var.upload(dens_var, m->n_dens));
+  m->n_mean = n_mean; m->n_var = n_var;
+  return SR_OK;
+}
+
+int sr_model_tying_info(const sr_model* m, uint32_t* n_mean, uint32_t* n_var) {
+  if (!m) return fail(SR_EINVAL, "null model handle");
+  if (n_mean) *n_mean = m->n_mean;
+  if (n_var) *n_var = m->n_var;
+  return SR_OK;
+}
+
+int sr_accumulate_corpus(sr_model* m, sr_corpus* c, const uint16_t* states, int first_pass, int max_approx, double* mean_acc,
+                         double* mean_w, double* var_acc, double* var_w) {
+  int rc = check_model(m);
+  if (rc) return rc;
+  if (!c || c->model != m) return fail(SR_EINVAL, "corpus does not belong to this model");
+  if (!mean_acc || !mean_w || !var_acc || !var_w) return fail(SR_EINVAL, "null output");
+  const uint64_t F = c->n_frames;
+  const uint32_t D = m->dim;
+  // empty result = reset_accumulators()
+  std::fill(mean_acc, mean_acc + (size_t)m->n_mean * D, 0.0);
+  std::fill(mean_w, mean_w + m->n_mean, 0.0);
+  std::fill(var_acc, var_acc + (size_t)m->n_var * D, 1e-4);
+  std::fill(var_w, var_w + m->n_var, 0.0);
+  if (F == 0) return SR_OK;
+  if (!states) return fail(SR_EINVAL, "states is null");
+  const bool soft = !first_pass && !max_approx;
+  std::vector<uint64_t> pair_off(F);
+  uint64_t n_pairs = 0;
+  for (uint64_t f = 0; f < F; f++) {
+    if (states[f] >= m->n_states) return fail(SR_EINVAL, "frame %llu: state %u >= n_states", (unsigned long long)f, states[f]);
+    pair_off[f] = n_pairs;
+    n_pairs += soft ? (m->h_dens_off[states[f] + 1] - m->h_dens_off[states[f]]) : 1;
+  }
+  if (n_pairs >= (1ull << 31)) return fail(SR_ELIMIT, "too many (frame, density) pairs");
+  if (n_pairs == 0) return SR_OK;
+  HIP_TRY(c->out_states.upload(states, F));
+  HIP_TRY(c->pair_off.upload(pair_off.data(), F));
+  HIP_TRY(c->pair_frame.ensure(n_pairs)); HIP_TRY(c->key_mean.ensure(n_pairs)); HIP_TRY(c->key_var.ensure(n_pairs));
+  HIP_TRY(c->pair_w.ensure(n_pairs)); HIP_TRY(c->keys_sorted.ensure(n_pairs)); HIP_TRY(c->pairs_sorted.ensure(n_pairs));
+  {
+    std::vector<uint32_t> iota(n_pairs);
+    std::iota(iota.begin(), iota.end(), 0u);
+    HIP_TRY(c->iota.upload(iota.data(), n_pairs));
+  }
+  const size_t temp = em_sort_temp_bytes(n_pairs);
+  HIP_TRY(c->sort_temp.ensure(temp));
+  HIP_TRY(c->acc_mean.ensure((size_t)m->n_mean * D)); HIP_TRY(c->w_mean.ensure(m->n_mean));
+  HIP_TRY(c->acc_var.ensure((size_t)m->n_var * D)); HIP_TRY(c->w_var.ensure(m->n_var));
+  EmArgs a{};
+  a.feats = c->feats.p; a.n_frames = F; a.n_pairs = n_pairs; a.dim = D; a.states = c->out_states.p; a.pair_off = c->pair_off.p;
+  a.dens_off = m->dens_off.p; a.means = m->means.p; a.inv_vars = m->inv_vars.p; a.norm = m->norm.p; a.logw = m->logw.p;
+  a.dens_mean = m->dens_mean.p; a.dens_var = m->dens_var.p; a.n_mean = m->n_mean; a.n_var = m->n_var;
+  a.first_pass = first_pass; a.max_approx = max_approx;
+  a.pair_frame = c->pair_frame.p; a.pair_w = c->pair_w.p; a.key_mean = c->key_mean.p; a.key_var = c->key_var.p;
+  EventPair ep{};
+  if ((rc = prof_begin(m, m->s_gmm, 1, &ep))) return rc;
+  HIP_TRY(launch_em_accumulate(a, c->sort_temp.p, temp, c->iota.p, c->keys_sorted.p, c->pairs_sorted.p, c->acc_mean.p, c->w_mean.p,
+                               c->acc_var.p, c->w_var.p, m->s_gmm));
+  if ((rc = prof_end(m, m->s_gmm, &ep))) return rc;
+  HIP_TRY(hipStreamSynchronize(m->s_gmm));
+  HIP_TRY(hipMemcpy(mean_acc, c->acc_mean.p, sizeof(double) * (size_t)m->n_mean * D, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(mean_w, c->w_mean.p, sizeof(double) * m->n_mean, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(var_acc, c->acc_var.p, sizeof(double) * (size_t)m->n_var * D, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(var_w, c->w_var.p, sizeof(double) * m->n_var, hipMemcpyDeviceToHost));
   return SR_OK;
 }
 

@@ -346,3 +346,58 @@ def test_path_scores_are_calc_am_score_summands(tmp_path, oracle_lib):
             corpus.path_scores(np.full(len(feats), lex.n_states, dtype=np.uint16))
         corpus.close()
     o.close()
+
+
+@pytest.mark.parametrize("tag,first_pass,max_approx", [("max", False, True), ("first", True, True), ("soft", False, False)])
+def test_em_accumulate_golden(tag, first_pass, max_approx, tmp_path):
+    """sr_accumulate_corpus against the REFERENCE's accumulators (tests/golden/accumulate.npz: tied variances, ragged
+    mixtures): bit-identical in max-approx and first-pass mode, 1e-12 with soft memberships (device exp)."""
+    from tests.test_oracle_golden import _accumulate_case
+    z, lex, spec, mp = _accumulate_case(tmp_path)
+    off = np.array([0, 200, 500], dtype=np.uint64)  # two "utterances"; accumulation ignores the boundary
+    with capi.Model.from_mixset(mp, 39, capi.POOL_NONE, max_approx) as m:
+        corpus = m.upload(z["feats"], off)
+        a, w, v, vw = corpus.accumulate(z["states"], first_pass=first_pass, max_approx=max_approx)
+        corpus.close()
+    keep = z["var_keep"]
+    if tag == "soft":
+        np.testing.assert_allclose(a, z[f"{tag}_mean_acc"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(w, z[f"{tag}_mean_w"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(v[keep], z[f"{tag}_var_acc"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(vw[keep], z[f"{tag}_var_w"], rtol=1e-12, atol=1e-12)
+    else:
+        assert np.array_equal(a.view(np.uint64), z[f"{tag}_mean_acc"].view(np.uint64)) and np.array_equal(w, z[f"{tag}_mean_w"])
+        assert np.array_equal(v[keep].view(np.uint64), z[f"{tag}_var_acc"].view(np.uint64)) and np.array_equal(vw[keep], z[f"{tag}_var_w"])
+        unused = np.setdiff1d(np.arange(len(vw)), keep)
+        assert np.all(vw[unused] == 0) and np.all(v[unused] == 1e-4)  # untouched rows = reset_accumulators()
+
+
+def test_em_accumulate_after_alignment_vs_oracle(tmp_path, oracle_lib):
+    """The training inner loop on the device: pruned re-alignment of a batch, then max-approx accumulation of that
+    alignment, against the oracle doing the same frame by frame."""
+    lex, spec, mp = _random_setup(tmp_path, 601, 25, 3, 1, (1, 6), 39)
+    rng = np.random.default_rng(602)
+    utts, auts = [], []
+    word_off, automaton, sil_state = lex.flatten()
+    for i in range(12):
+        ws = rng.integers(1, lex.n_words, size=3)
+        utts.append(synth.sample_utterance(spec, lex, ws, seed=610 + i))
+        a = [sil_state]
+        for w in ws:
+            a += list(automaton[word_off[w]:word_off[w + 1]]) + [sil_state]
+        auts.append(np.asarray(a, dtype=np.uint16))
+    off = np.concatenate([[0], np.cumsum([len(u) for u in utts])]).astype(np.uint64)
+    feats = np.concatenate(utts)
+    o = oracle_lib.Oracle(mp, 39, lex)
+    with capi.Model.from_mixset(mp, 39) as m:
+        corpus = m.upload(feats, off)
+        states, _ = corpus.align(auts, (3.0, 0.0, 30.0), sil_state, capi.GMM_EXACT, pruning_threshold=50.0)
+        want_states = np.concatenate([o.align_pruned(u, a, 50.0)[0] for u, a in zip(utts, auts)])
+        assert np.array_equal(states, want_states)
+        got = corpus.accumulate(states)
+        want = o.accumulate(feats, want_states)
+        for g, wv in zip(got, want):
+            assert np.array_equal(g.view(np.uint64), wv.view(np.uint64))
+        assert got[1].sum() == len(feats)
+        corpus.close()
+    o.close()

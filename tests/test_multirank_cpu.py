@@ -40,6 +40,17 @@ def _worker(rank, world, port, mixset, tmpdir):
     words, woff, secs = orc.recognize_batch(sub, sub_off, n_threads=1)
     gathered = sharding.gather_words(words, woff, mine, 11, dist)
     t, f = sharding.reduce_timing(0.5 + rank, float(sub_off[-1]), dist)
+    # EM statistics: each rank accumulates its shard, one all-reduce gives the corpus statistics
+    states = np.concatenate([np.random.default_rng(100 + int(u)).integers(0, lex.n_states, size=int(off[u + 1] - off[u]))
+                             for u in mine]).astype(np.uint16) if len(mine) else np.zeros(0, np.uint16)
+    acc = sharding.allreduce_accumulators(orc.accumulate(sub, states), dist)
+    if rank == 0:
+        all_states = np.concatenate([np.random.default_rng(100 + u).integers(0, lex.n_states, size=int(off[u + 1] - off[u]))
+                                     for u in range(11)]).astype(np.uint16)
+        want = orc.accumulate(feats, all_states)
+        for g, w_ in zip(acc, want):
+            np.testing.assert_allclose(g, w_, rtol=1e-12, atol=1e-12)
+        assert acc[1].sum() == float(off[-1])
     if rank == 0:
         assert t == 0.5 + (world - 1) and f == float(off[-1])
         for u in range(11):
