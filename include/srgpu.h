@@ -66,6 +66,17 @@ SR_API int sr_model_create(int device, uint32_t dim, uint32_t n_states, const ui
  * device model.  pooling: 0 global, 1 mixture, 2 none (MixtureModel::VarianceModel, Mixtures.hpp:20-24).
  * Malformed files return SR_EINVAL with the reference's message instead of abort() (Mixtures.cpp:97-102). */
 SR_API int sr_model_load_mixset(const char* path, uint32_t dim, int pooling, int max_approx, int device, sr_model** out);
+/* MixtureModel::finalize (Mixtures.cpp:374-461) on in-memory statistics -- the model update of an EM iteration:
+ * accumulators as sr_accumulate_corpus returns them (+ the topology: dens_off, accumulator rows per density) ->
+ * new device model.  sr_mixset_write stores the same statistics as a MIXSET v2 file exactly like
+ * MixtureModel::write (Mixtures.cpp:834-878: unreferenced rows dropped and renumbered). */
+SR_API int sr_model_create_from_statistics(int device, uint32_t dim, uint32_t n_states, const uint32_t* dens_off,
+                                           uint32_t n_mean, uint32_t n_var, const uint32_t* dens_mean, const uint32_t* dens_var,
+                                           const double* mean_acc, const double* mean_w, const double* var_acc, const double* var_w,
+                                           int pooling, int max_approx, sr_model** out);
+SR_API int sr_mixset_write(const char* path, uint32_t dim, uint32_t n_states, const uint32_t* dens_off, uint32_t n_mean,
+                           uint32_t n_var, const uint32_t* dens_mean, const uint32_t* dens_var, const double* mean_acc,
+                           const double* mean_w, const double* var_acc, const double* var_w);
 SR_API int sr_model_destroy(sr_model* m);
 SR_API int sr_model_info(const sr_model* m, uint32_t* dim, uint32_t* n_states, uint64_t* n_densities);
 

@@ -21,7 +21,7 @@ POOL_GLOBAL, POOL_MIXTURE, POOL_NONE = 0, 1, 2
 SYMBOLS = [
     "sr_last_error", "sr_device_count", "sr_model_create", "sr_model_load_mixset", "sr_model_destroy", "sr_model_info",
     "sr_corpus_upload", "sr_corpus_destroy", "sr_score_corpus", "sr_score_frames", "sr_lexicon_create",
-    "sr_lexicon_destroy", "sr_recognize_corpus", "sr_recognize_batch", "sr_align_corpus", "sr_align_corpus_pruned", "sr_path_scores_corpus", "sr_model_set_tying", "sr_model_tying_info", "sr_accumulate_corpus",
+    "sr_lexicon_destroy", "sr_recognize_corpus", "sr_recognize_batch", "sr_align_corpus", "sr_align_corpus_pruned", "sr_path_scores_corpus", "sr_model_create_from_statistics", "sr_mixset_write", "sr_model_set_tying", "sr_model_tying_info", "sr_accumulate_corpus",
     "sr_profile_enable", "sr_profile_reset", "sr_profile_read",
 ]
 
@@ -70,6 +70,8 @@ def lib():
         L.sr_align_corpus.argtypes = [vp, vp, vp, vp, C.POINTER(dbl * 3), C.c_uint16, i32, vp, vp]
         L.sr_align_corpus_pruned.argtypes = [vp, vp, vp, vp, C.POINTER(dbl * 3), C.c_uint16, dbl, i32, vp, vp]
         L.sr_path_scores_corpus.argtypes = [vp, vp, vp, i32, vp]
+        L.sr_model_create_from_statistics.argtypes = [i32, u32, u32, vp, u32, u32, vp, vp, vp, vp, vp, vp, i32, i32, C.POINTER(vp)]
+        L.sr_mixset_write.argtypes = [C.c_char_p, u32, u32, vp, u32, u32, vp, vp, vp, vp, vp, vp]
         L.sr_model_set_tying.argtypes = [vp, u32, u32, vp, vp]
         L.sr_model_tying_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
         L.sr_accumulate_corpus.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp]
@@ -120,6 +122,17 @@ class Model:
         h = C.c_void_p()
         _check(lib().sr_model_create(device, means.shape[1], len(dens_off) - 1, _ptr(dens_off), _ptr(means), _ptr(inv_vars),
                                      _ptr(norm), _ptr(logw), int(max_approx), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_statistics(cls, dim, dens_off, dens_mean, dens_var, acc, pooling=POOL_NONE, max_approx=True, device=0):
+        """MixtureModel::finalize on EM statistics `acc` = (mean_acc, mean_w, var_acc, var_w) -> new device model."""
+        dens_off, dens_mean, dens_var = (np.ascontiguousarray(x, dtype=np.uint32) for x in (dens_off, dens_mean, dens_var))
+        ma, mw, va, vw = (np.ascontiguousarray(x, dtype=np.float64) for x in acc)
+        h = C.c_void_p()
+        _check(lib().sr_model_create_from_statistics(device, dim, len(dens_off) - 1, _ptr(dens_off), len(mw), len(vw), _ptr(dens_mean),
+                                                     _ptr(dens_var), _ptr(ma), _ptr(mw), _ptr(va), _ptr(vw), pooling, int(max_approx),
+                                                     C.byref(h)))
         return cls(h)
 
     def close(self):
@@ -249,3 +262,11 @@ class Lexicon:
         if self.h:
             lib().sr_lexicon_destroy(self.h)
             self.h = None
+
+
+def mixset_write(path, dim, dens_off, dens_mean, dens_var, acc):
+    """MixtureModel::write: EM statistics + topology -> MIXSET v2 file."""
+    dens_off, dens_mean, dens_var = (np.ascontiguousarray(x, dtype=np.uint32) for x in (dens_off, dens_mean, dens_var))
+    ma, mw, va, vw = (np.ascontiguousarray(x, dtype=np.float64) for x in acc)
+    _check(lib().sr_mixset_write(str(path).encode(), dim, len(dens_off) - 1, _ptr(dens_off), len(mw), len(vw), _ptr(dens_mean),
+                                 _ptr(dens_var), _ptr(ma), _ptr(mw), _ptr(va), _ptr(vw)))

@@ -48,11 +48,18 @@ const char* read_block(Reader& r, uint32_t dim, Accumulators* a) {
 
 struct Density { uint32_t mean, var; };
 
+// accumulator-level content of a model: what MixtureModel holds besides the derived tables
+struct Mixset {
+  uint32_t dim = 0;
+  Accumulators mean_acc, var_acc;
+  std::vector<std::vector<Density>> mixtures;
+};
+
 }  // namespace
 
 namespace srhost {
 
-const char* load_mixset(const char* path, uint32_t dim, int pooling, MixsetTables* out) {
+static const char* parse_mixset(const char* path, uint32_t dim, Mixset* ms) {
   Reader r(path);
   if (!r.f) return "cannot open model file";
   char magic[8];
@@ -64,7 +71,9 @@ const char* load_mixset(const char* path, uint32_t dim, int pooling, MixsetTable
   if (version != 2u) return "Invalid version";
   if (!r.get(&fdim)) return "Error reading dimension";
   if (fdim != dim) return "Invalid dimension";
-  Accumulators mean_acc, var_acc;
+  Accumulators& mean_acc = ms->mean_acc;
+  Accumulators& var_acc = ms->var_acc;
+  ms->dim = dim;
   if (const char* e = read_block(r, dim, &mean_acc)) return e;
   if (const char* e = read_block(r, dim, &var_acc)) return e;
   uint32_t n_dens = 0;
@@ -78,7 +87,8 @@ const char* load_mixset(const char* path, uint32_t dim, int pooling, MixsetTable
   }
   uint32_t n_mix = 0;
   if (!r.get(&n_mix)) return "Error reading mixture count";
-  std::vector<std::vector<Density>> mixtures(n_mix);
+  std::vector<std::vector<Density>>& mixtures = ms->mixtures;
+  mixtures.assign(n_mix, std::vector<Density>());
   for (auto& mix : mixtures) {
     uint32_t nd = 0;
     if (!r.get(&nd)) return "Error reading density count for mixture";
@@ -93,6 +103,15 @@ const char* load_mixset(const char* path, uint32_t dim, int pooling, MixsetTable
       mix.push_back(dens[di]);
     }
   }
+  return nullptr;
+}
+
+// MixtureModel::finalize (Mixtures.cpp:374-461)
+static void finalize_mixset(const Mixset& ms, int pooling, MixsetTables* out) {
+  const uint32_t dim = ms.dim;
+  const Accumulators& mean_acc = ms.mean_acc;
+  const Accumulators& var_acc = ms.var_acc;
+  const std::vector<std::vector<Density>>& mixtures = ms.mixtures;
 
   // ---- finalize ----------------------------------------------------------------------------------
   const size_t D = dim;
@@ -152,17 +171,81 @@ const char* load_mixset(const char* path, uint32_t dim, int pooling, MixsetTable
     }
     out->dens_off.push_back((uint32_t)out->norm.size());
   }
+}
+
+const char* load_mixset(const char* path, uint32_t dim, int pooling, MixsetTables* out) {
+  Mixset ms;
+  if (const char* e = parse_mixset(path, dim, &ms)) return e;
+  finalize_mixset(ms, pooling, out);
   return nullptr;
+}
+
+// in-memory statistics (flattened topology) -> Mixset; returns an error text or nullptr
+static const char* mixset_from_arrays(uint32_t dim, uint32_t n_states, const uint32_t* dens_off, uint32_t n_mean, uint32_t n_var,
+                                      const uint32_t* dens_mean, const uint32_t* dens_var, const double* mean_acc, const double* mean_w,
+                                      const double* var_acc, const double* var_w, Mixset* ms) {
+  if (!dens_off || !dens_mean || !dens_var || !mean_acc || !mean_w || !var_acc || !var_w) return "null argument";
+  ms->dim = dim;
+  ms->mean_acc.n = n_mean; ms->mean_acc.sum.assign(mean_acc, mean_acc + (size_t)n_mean * dim); ms->mean_acc.weight.assign(mean_w, mean_w + n_mean);
+  ms->var_acc.n = n_var; ms->var_acc.sum.assign(var_acc, var_acc + (size_t)n_var * dim); ms->var_acc.weight.assign(var_w, var_w + n_var);
+  ms->mixtures.assign(n_states, std::vector<Density>());
+  for (uint32_t s = 0; s < n_states; s++) {
+    if (dens_off[s + 1] < dens_off[s]) return "dens_off must be non-decreasing";
+    for (uint32_t c = dens_off[s]; c < dens_off[s + 1]; c++) {
+      if (dens_mean[c] >= n_mean || dens_var[c] >= n_var) return "tying index out of range";
+      ms->mixtures[s].push_back(Density{dens_mean[c], dens_var[c]});
+    }
+  }
+  return nullptr;
+}
+
+// MixtureModel::write (Mixtures.cpp:834-878): rows no density references are dropped and the rest renumbered
+// (build_mapping, :83-95); densities are listed in mixture order, so density_idx is a running counter
+static const char* write_mixset_file(const char* path, const Mixset& ms) {
+  FILE* f = fopen(path, "wb");
+  if (!f) return "cannot open output file";
+  const uint32_t D = ms.dim;
+  std::vector<uint32_t> mean_refs(ms.mean_acc.n, 0), var_refs(ms.var_acc.n, 0), mean_map(ms.mean_acc.n, 0), var_map(ms.var_acc.n, 0);
+  for (auto& mix : ms.mixtures)
+    for (const Density& dn : mix) { mean_refs[dn.mean]++; var_refs[dn.var]++; }
+  uint32_t mean_count = 0, var_count = 0;
+  for (uint32_t i = 0; i < ms.mean_acc.n; i++) if (mean_refs[i]) mean_map[i] = mean_count++;
+  for (uint32_t i = 0; i < ms.var_acc.n; i++) if (var_refs[i]) var_map[i] = var_count++;
+  static const char kMagic[8] = {'M', 'I', 'X', 'S', 'E', 'T', 0, 0};
+  const uint32_t version = 2;
+  fwrite(kMagic, 1, 8, f); fwrite(&version, 4, 1, f); fwrite(&D, 4, 1, f);
+  auto block = [&](const Accumulators& a, const std::vector<uint32_t>& refs, uint32_t count) {
+    fwrite(&count, 4, 1, f);
+    for (uint32_t i = 0; i < a.n; i++) {
+      if (!refs[i]) continue;
+      fwrite(&D, 4, 1, f);
+      fwrite(a.sum.data() + (size_t)i * D, sizeof(double), D, f);
+      fwrite(&a.weight[i], sizeof(double), 1, f);
+    }
+  };
+  block(ms.mean_acc, mean_refs, mean_count);
+  block(ms.var_acc, var_refs, var_count);
+  uint32_t density_count = 0;
+  for (auto& mix : ms.mixtures) density_count += (uint32_t)mix.size();
+  fwrite(&density_count, 4, 1, f);
+  for (auto& mix : ms.mixtures)
+    for (const Density& dn : mix) { fwrite(&mean_map[dn.mean], 4, 1, f); fwrite(&var_map[dn.var], 4, 1, f); }
+  const uint32_t mixture_count = (uint32_t)ms.mixtures.size();
+  fwrite(&mixture_count, 4, 1, f);
+  uint32_t running = 0;
+  for (auto& mix : ms.mixtures) {
+    const uint32_t nd = (uint32_t)mix.size();
+    fwrite(&nd, 4, 1, f);
+    for (const Density& dn : mix) { fwrite(&running, 4, 1, f); fwrite(&ms.mean_acc.weight[dn.mean], sizeof(double), 1, f); running++; }
+  }
+  const bool ok = !ferror(f);
+  fclose(f);
+  return ok ? nullptr : "write error";
 }
 
 }  // namespace srhost
 
-extern "C" SR_API int sr_model_load_mixset(const char* path, uint32_t dim, int pooling, int max_approx, int device,
-                                           sr_model** out) {
-  if (!path || !out) return srhost::set_error(SR_EINVAL, "null argument");
-  if (pooling < 0 || pooling > 2) return srhost::set_error(SR_EINVAL, "pooling must be 0 (global), 1 (mixture) or 2 (none)");
-  srhost::MixsetTables t;
-  if (const char* e = srhost::load_mixset(path, dim, pooling, &t)) return srhost::set_error(SR_EINVAL, e);
+static int tables_to_model(const srhost::MixsetTables& t, uint32_t dim, int max_approx, int device, sr_model** out) {
   int rc = sr_model_create(device, dim, (uint32_t)t.dens_off.size() - 1, t.dens_off.data(), t.means.data(), t.inv_vars.data(),
                            t.norm.data(), t.logw.data(), max_approx, out);
   if (rc == SR_OK && !t.dens_mean.empty()) {
@@ -170,4 +253,39 @@ extern "C" SR_API int sr_model_load_mixset(const char* path, uint32_t dim, int p
     if (rc != SR_OK) { sr_model_destroy(*out); *out = nullptr; }
   }
   return rc;
+}
+
+extern "C" SR_API int sr_model_create_from_statistics(int device, uint32_t dim, uint32_t n_states, const uint32_t* dens_off,
+                                                      uint32_t n_mean, uint32_t n_var, const uint32_t* dens_mean,
+                                                      const uint32_t* dens_var, const double* mean_acc, const double* mean_w,
+                                                      const double* var_acc, const double* var_w, int pooling, int max_approx,
+                                                      sr_model** out) {
+  if (!out) return srhost::set_error(SR_EINVAL, "out is null");
+  if (pooling < 0 || pooling > 2) return srhost::set_error(SR_EINVAL, "pooling must be 0 (global), 1 (mixture) or 2 (none)");
+  Mixset ms;
+  if (const char* e = srhost::mixset_from_arrays(dim, n_states, dens_off, n_mean, n_var, dens_mean, dens_var, mean_acc, mean_w, var_acc, var_w, &ms))
+    return srhost::set_error(SR_EINVAL, e);
+  srhost::MixsetTables t;
+  srhost::finalize_mixset(ms, pooling, &t);
+  return tables_to_model(t, dim, max_approx, device, out);
+}
+
+extern "C" SR_API int sr_mixset_write(const char* path, uint32_t dim, uint32_t n_states, const uint32_t* dens_off, uint32_t n_mean,
+                                      uint32_t n_var, const uint32_t* dens_mean, const uint32_t* dens_var, const double* mean_acc,
+                                      const double* mean_w, const double* var_acc, const double* var_w) {
+  if (!path) return srhost::set_error(SR_EINVAL, "path is null");
+  Mixset ms;
+  if (const char* e = srhost::mixset_from_arrays(dim, n_states, dens_off, n_mean, n_var, dens_mean, dens_var, mean_acc, mean_w, var_acc, var_w, &ms))
+    return srhost::set_error(SR_EINVAL, e);
+  if (const char* e = srhost::write_mixset_file(path, ms)) return srhost::set_error(SR_EINVAL, e);
+  return SR_OK;
+}
+
+extern "C" SR_API int sr_model_load_mixset(const char* path, uint32_t dim, int pooling, int max_approx, int device,
+                                           sr_model** out) {
+  if (!path || !out) return srhost::set_error(SR_EINVAL, "null argument");
+  if (pooling < 0 || pooling > 2) return srhost::set_error(SR_EINVAL, "pooling must be 0 (global), 1 (mixture) or 2 (none)");
+  srhost::MixsetTables t;
+  if (const char* e = srhost::load_mixset(path, dim, pooling, &t)) return srhost::set_error(SR_EINVAL, e);
+  return tables_to_model(t, dim, max_approx, device, out);
 }

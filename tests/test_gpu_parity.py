@@ -401,3 +401,32 @@ def test_em_accumulate_after_alignment_vs_oracle(tmp_path, oracle_lib):
         assert got[1].sum() == len(feats)
         corpus.close()
     o.close()
+
+
+def test_em_iteration_matches_reference_model_file(tmp_path, oracle_lib):
+    """One EM iteration on the device -- accumulate an alignment, write the statistics as a MIXSET file
+    (MixtureModel::write), finalise them into a new device model (MixtureModel::finalize) -- against the
+    REFERENCE's accumulate + write golden: the files must be byte-identical and the updated model's scores
+    bit-identical to what the oracle computes after loading that file."""
+    from tests.test_oracle_golden import _accumulate_case
+    z, lex, spec, mp = _accumulate_case(tmp_path)
+    dens_off = np.concatenate([[0], np.cumsum([len(m) for m in spec.mixtures])]).astype(np.uint32)
+    flat = np.asarray([d for m in spec.mixtures for d in m], dtype=np.int64)
+    dens_mean, dens_var = spec.dens_mean[flat], spec.dens_var[flat]
+    with capi.Model.from_mixset(mp, 39) as m:
+        corpus = m.upload(z["feats"], np.array([0, 500], dtype=np.uint64))
+        acc = corpus.accumulate(z["states"])
+        corpus.close()
+    out = str(tmp_path / "updated.mix")
+    capi.mixset_write(out, 39, dens_off, dens_mean, dens_var, acc)
+    got = synth.read_mixset(out)
+    assert np.array_equal(got.mean_acc, z["max_mean_acc"]) and np.array_equal(got.mean_w, z["max_mean_w"])
+    assert np.array_equal(got.var_acc, z["max_var_acc"]) and np.array_equal(got.var_w, z["max_var_w"])
+    # states that received no frames have zero weight -> NaN parameters -> 1e10 scores, same as the reference
+    o = oracle_lib.Oracle(out, 39, lex)
+    want = o.score_matrix(z["feats"][:64])
+    o.close()
+    with capi.Model.from_statistics(39, dens_off, dens_mean, dens_var, acc) as m2:
+        got_scores = m2.score_frames(z["feats"][:64], capi.GMM_EXACT)
+        assert np.array_equal(got_scores.view(np.uint64), want.view(np.uint64))
+        _assert_scores_close(m2.score_frames(z["feats"][:64], capi.GMM_MFMA), want)
