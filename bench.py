@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--words", type=int, default=1333, help="three-state words (states = 1 + 3*words)")
     ap.add_argument("--mix", type=int, default=32)
     ap.add_argument("--beam", type=float, default=200.0)
-    ap.add_argument("--kernel", choices=["mfma", "exact"], default="mfma")
+    ap.add_argument("--kernel", choices=["mfma", "exact", "prefilter"], default="mfma")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals "
                     "where several ranks share one GPU)")
@@ -83,7 +83,7 @@ def main():
     feats, frame_off = synth.make_batch(args.utts, 200, 400, D, seed=7 + 1000 * rank)  # this rank's shard
     n_frames = int(frame_off[-1])
     word_off, automaton, sil_state = lex.flatten()
-    kernel = capi.GMM_MFMA if args.kernel == "mfma" else capi.GMM_EXACT
+    kernel = {"mfma": capi.GMM_MFMA, "exact": capi.GMM_EXACT, "prefilter": capi.GMM_PREFILTER}[args.kernel]
 
     model = capi.Model.from_mixset(mixset_path, D, capi.POOL_NONE, True, device=device)
     lexh = model.lexicon(word_off, automaton, lex.silence_idx, tdp, sil_state)
@@ -162,6 +162,9 @@ def main():
             },
             "recognised_words_rank0": int(woff[-1]),
         }
+        if prof.get("refined_pairs"):
+            out["prefilter"] = {"densities_refined_per_pair": prof["refined_densities"] / prof["refined_pairs"],
+                                "of": args.mix}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, mixset_path, lex, tdp, wp, feats, frame_off, words, woff)
         print(json.dumps(out))

@@ -43,6 +43,9 @@ extern "C" {
 /* GMM scoring kernels (MixtureModel::score, Mixtures.cpp:737-744) */
 #define SR_GMM_MFMA 0   /* FP64 MFMA contraction + fused min / log-sum epilogue (default; ~1e-15 rel.) */
 #define SR_GMM_EXACT 1  /* direct form replaying density_score_sse's operation order (Mixtures.cpp:645-690): bit-exact */
+#define SR_GMM_PREFILTER 2  /* bit-exact like SR_GMM_EXACT: a bf16 MFMA prefilter selects the densities that can be the
+                               minimum, FP64 replays only those.  Max-approx models with <= 32 densities per mixture and
+                               dim <= 47; any other model is scored by SR_GMM_EXACT's kernel instead (same bits). */
 
 typedef struct sr_model sr_model;     /* replaces MixtureModel as a FeatureScorer (Mixtures.hpp:18, FeatureScorer.hpp:12-16) */
 typedef struct sr_corpus sr_corpus;   /* replaces Corpus' feature store (Corpus.hpp:79-84, Corpus.cpp:141-144) */
@@ -108,7 +111,7 @@ SR_API int sr_lexicon_destroy(sr_lexicon* l);
 typedef struct {
   double am_threshold; /* "am-threshold", Recognizer.cpp:31 (beam) */
   double word_penalty; /* "word-penalty", Recognizer.cpp:32 */
-  int gmm_kernel;      /* SR_GMM_MFMA or SR_GMM_EXACT */
+  int gmm_kernel;      /* SR_GMM_MFMA, SR_GMM_EXACT or SR_GMM_PREFILTER */
   int reserved;
 } sr_search_params;
 
@@ -172,6 +175,8 @@ typedef struct {
   uint64_t search_launches;
   double search_bytes;  /* algorithmic: (8*S + 4*P) * frames (decode) / (8+1)*N * frames (align) */
   uint64_t frames;      /* frames processed */
+  uint64_t refined_pairs;      /* SR_GMM_PREFILTER: (frame, state) pairs scored ... */
+  uint64_t refined_densities;  /* ... and densities the FP64 stage had to evaluate for them (>= 1 per pair) */
 } sr_profile;
 SR_API int sr_profile_enable(sr_model* m, int on);
 SR_API int sr_profile_reset(sr_model* m);

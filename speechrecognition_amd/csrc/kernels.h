@@ -39,6 +39,35 @@ struct GmmExactArgs {
 };
 hipError_t launch_gmm_exact(const GmmExactArgs& a, bool sum, uint32_t n_splits, hipStream_t stream);
 
+// ---- exact GMM scoring through a bf16 prefilter (gmm_prefilter.hip) ------------------------------------------------
+struct GmmPrefilterArgs {
+  const float* feats;
+  uint64_t n_frames;
+  uint32_t dim;
+  const unsigned char* apack;   // [n_groups*8 blocks][KS32][hi/lo][64 lanes][8 bf16]
+  const float* grp_anorm;       // [n_groups*4] largest coefficient norm of the state in that slot
+  const uint32_t* split_begin;  // [ny+1] group ranges
+  uint32_t* mask;               // [group][frame][4 state slots] candidate densities of (frame, state)
+  uint32_t nx, ny;
+};
+struct GmmRefineArgs {
+  const float* featsT;          // [dim x n_frames_ld] transposed features
+  uint64_t n_frames, n_frames_ld;
+  uint32_t dim, n_states, max_dens;
+  const uint32_t* dens_off;
+  const double* rows;           // [C][row_stride]: mu_0, 1/var_0, ..., mu_{D-1}, 1/var_{D-1}, norm, logw, padding;
+                                // 1 KB of slack after the last row
+  uint32_t row_stride;          // doubles; row_stride/2 odd and >= dim + 1
+  const uint32_t* mask;         // as written by the prefilter
+  double* out; uint32_t ld;
+  uint32_t states_per_split;
+  unsigned long long* n_refined;  // optional: += densities evaluated (profiling)
+};
+hipError_t launch_gmm_prefilter(const GmmPrefilterArgs& a, int ks32, hipStream_t stream);
+int gmm_prefilter_frames_per_tile();
+hipError_t launch_gmm_refine(const GmmRefineArgs& a, uint32_t n_splits, hipStream_t stream);
+hipError_t launch_transpose_feats(const float* feats, uint64_t n_frames, uint32_t dim, uint64_t ldT, float* out, hipStream_t stream);
+
 // ---- beam Viterbi decoder (viterbi_decode.hip) ---------------------------------------------------
 // Search network flattened to "slots" = (word, position) pairs in (word, position) order, which is
 // the iteration order of the reference's hypothesis array (Recognizer.cpp:126).

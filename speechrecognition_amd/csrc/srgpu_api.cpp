@@ -91,6 +91,14 @@ struct sr_model {
   std::vector<uint32_t> group_first_block;  // host: [n_groups+1]
   DevBuf<uint32_t> split_begin;
   uint32_t split_ny = 0;
+  // bf16 prefilter + FP64 refinement (gmm_prefilter.hip); pf_ks32 == 0: model not eligible
+  int pf_ks32 = 0;
+  uint32_t pf_groups = 0, pf_ny = 0, max_dens = 0, pf_row_stride = 0;
+  DevBuf<unsigned char> pf_apack;
+  DevBuf<float> pf_anorm, featsT;
+  DevBuf<uint32_t> pf_split, pf_mask;
+  DevBuf<double> pf_rows;
+  DevBuf<unsigned long long> pf_counter;
   // streams / workspace
   hipStream_t s_gmm = nullptr, s_search = nullptr;
   DevBuf<double> scores[2];
@@ -212,6 +220,112 @@ int pack_model(sr_model* m, const uint32_t* dens_off, const double* means, const
   return SR_OK;
 }
 
+// ---- model packing for the bf16 prefilter ---------------------------------------------------------------------
+// Groups of four states in natural order, each padded to 8 blocks of 16 rows (32 density slots per state); row r of
+// block j = density 4*j + (r & 3) of state slot (r >> 2).  Every coefficient is split into two bf16 terms
+// (round-to-nearest-even); fragment order [block][k-step of 32][hi, lo][lane][8]: lane l holds row l & 15,
+// k = 32*ks + 8*(l >> 4) + j -- the A operand of v_mfma_f32_16x16x32_bf16.
+uint16_t bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)((u >> 16) | ((u & 0xFFFFu) ? 0x40u : 0u));  // inf / NaN
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+float bf16_to_float(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, const double* inv_vars,
+                   const double* norm, const double* logw) {
+  const uint32_t S = m->n_states, D = m->dim;
+  uint32_t mx = 0;
+  for (uint32_t s = 0; s < S; s++) mx = std::max(mx, dens_off[s + 1] - dens_off[s]);
+  m->max_dens = std::max(1u, mx);
+  // FP64 rows for the refinement: [density][mu_0, 1/var_0, ..., norm, logw, padding]; an odd number of 16-byte pieces
+  // per row spreads a wave's row gather over all LDS banks; 1 KB of slack for the LDS-DMA's last piece
+  {
+    uint32_t q = D + 1;
+    if ((q & 1u) == 0) q++;
+    m->pf_row_stride = 2 * q;
+    std::vector<double> rows((size_t)m->n_dens * m->pf_row_stride + 128, 0.0);
+    for (size_t c = 0; c < (size_t)m->n_dens; c++) {
+      double* r = rows.data() + c * m->pf_row_stride;
+      for (uint32_t d = 0; d < D; d++) { r[2 * d] = means[c * D + d]; r[2 * d + 1] = inv_vars[c * D + d]; }
+      r[2 * D] = norm[c];
+      r[2 * D + 1] = logw[c];
+    }
+    HIP_TRY(m->pf_rows.upload(rows.data(), rows.size()));
+  }
+  m->pf_ks32 = 0;
+  if (!m->max_approx || mx > 32 || 2 * D + 1 > 96) return SR_OK;  // not eligible: callers get the exact kernel
+  const int KS = (int)((2 * D + 1 + 31) / 32);
+  const uint32_t n_groups = (S + 3) / 4;
+  const size_t blk_bytes = (size_t)KS * 2 * 1024;
+  std::vector<uint16_t> ap((size_t)n_groups * 8 * blk_bytes / 2, 0);
+  std::vector<float> anorm(4 * (size_t)n_groups, 0.0f);
+  std::vector<double> arow(32 * (size_t)KS);
+  for (uint32_t q = 0; q < n_groups; q++) {
+    for (uint32_t j = 0; j < 8; j++) {
+      const size_t b = (size_t)q * 8 + j;
+      for (uint32_t r = 0; r < 16; r++) {
+        const uint32_t g = r >> 2, st = 4 * q + g, i = 4 * j + (r & 3);
+        const bool real = st < S && i < dens_off[st + 1] - dens_off[st];
+        std::fill(arow.begin(), arow.end(), 0.0);
+        if (real) {
+          const size_t c = (size_t)dens_off[st] + i;
+          double q2 = 0.0, n2 = 0.0;
+          for (uint32_t d = 0; d < D; d++) {
+            const double mu = means[c * D + d], iv = inv_vars[c * D + d];
+            arow[2 * d] = 0.5 * iv;
+            arow[2 * d + 1] = -mu * iv;
+            q2 += mu * mu * iv;
+          }
+          arow[2 * D] = norm[c] - logw[c] + 0.5 * q2;
+          for (uint32_t k = 0; k <= 2 * D; k++) n2 += arow[k] * arow[k];
+          const float na = std::nextafter((float)(std::sqrt(n2) * (1.0 + 1e-6)), std::numeric_limits<float>::infinity());
+          if (!(na <= anorm[4 * q + g])) anorm[4 * q + g] = na;  // NaN sticks: everything of that state stays a candidate
+        } else {
+          arow[2 * D] = 3.0e38;  // padding slot: never below a real score, masked off again by the refinement
+        }
+        for (int ks = 0; ks < KS; ks++)
+          for (uint32_t kk = 0; kk < 32; kk++) {
+            const double v = arow[32 * ks + kk];
+            const uint16_t hi = bf16_rne((float)v);
+            const uint16_t lo = real ? bf16_rne((float)(v - (double)bf16_to_float(hi))) : (uint16_t)0;
+            const uint32_t lane = r + 16 * (kk >> 3), e = kk & 7;
+            const size_t base = (b * blk_bytes) / 2 + (size_t)ks * 1024 + (size_t)lane * 8 + e;
+            ap[base] = hi;
+            ap[base + 512] = lo;
+          }
+      }
+    }
+  }
+  HIP_TRY(m->pf_apack.upload(reinterpret_cast<const unsigned char*>(ap.data()), ap.size() * 2));
+  HIP_TRY(m->pf_anorm.upload(anorm.data(), anorm.size()));
+  m->pf_groups = n_groups;
+  m->pf_ks32 = KS;
+  m->pf_ny = 0;
+  return SR_OK;
+}
+
+int set_prefilter_splits(sr_model* m, uint32_t nx) {
+  const uint32_t target_wgs = 16 * 768;
+  uint32_t ny = (target_wgs + nx - 1) / std::max(1u, nx);
+  ny = std::max(1u, std::min(ny, std::max(1u, m->pf_groups / 8)));
+  if (ny >= 8) ny &= ~7u;
+  if (ny == m->pf_ny) return SR_OK;
+  std::vector<uint32_t> sb(ny + 1);
+  for (uint32_t y = 0; y <= ny; y++) sb[y] = (uint32_t)((uint64_t)m->pf_groups * y / ny);
+  HIP_TRY(hipStreamSynchronize(m->s_gmm));
+  HIP_TRY(m->pf_split.upload(sb.data(), sb.size()));
+  m->pf_ny = ny;
+  return SR_OK;
+}
+
 // choose the state-range split count for a launch over `nx` frame tiles and upload group-aligned ranges
 int set_splits(sr_model* m, uint32_t nx) {
   // Equal-sized workgroups run in rounds of (2 per CU x 256 CUs); aim for ~32 rounds so the last,
@@ -268,7 +382,36 @@ int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm
     if ((rc = prof_begin(m, m->s_gmm, 0, &ep))) return rc;
     HIP_TRY(launch_gmm_mfma(a, m->ksteps, !m->max_approx, m->s_gmm));
     if ((rc = prof_end(m, m->s_gmm, &ep))) return rc;
-  } else if (gmm_kernel == SR_GMM_EXACT) {
+  } else if (gmm_kernel == SR_GMM_PREFILTER && m->pf_ks32 > 0) {
+    const uint32_t tile = gmm_prefilter_frames_per_tile();
+    const uint32_t nx = (uint32_t)((n_frames + tile - 1) / tile);
+    int rc = set_prefilter_splits(m, nx);
+    if (rc) return rc;
+    const uint64_t ldT = (n_frames + 63) & ~(uint64_t)63;
+    HIP_TRY(m->featsT.ensure((size_t)ldT * m->dim));
+    HIP_TRY(m->pf_mask.ensure((size_t)m->pf_groups * n_frames * 4));
+    GmmPrefilterArgs pa{};
+    pa.feats = d_feats; pa.n_frames = n_frames; pa.dim = m->dim;
+    pa.apack = m->pf_apack.p; pa.grp_anorm = m->pf_anorm.p; pa.split_begin = m->pf_split.p;
+    pa.mask = m->pf_mask.p; pa.nx = nx; pa.ny = m->pf_ny;
+    GmmRefineArgs ra{};
+    ra.featsT = m->featsT.p; ra.n_frames = n_frames; ra.n_frames_ld = ldT; ra.dim = m->dim; ra.n_states = m->n_states;
+    ra.max_dens = m->max_dens; ra.dens_off = m->dens_off.p; ra.rows = m->pf_rows.p; ra.row_stride = m->pf_row_stride;
+    ra.mask = m->pf_mask.p; ra.out = d_out; ra.ld = m->ld;
+    ra.n_refined = m->profiling ? m->pf_counter.p : nullptr;
+    if (m->profiling) m->prof.refined_pairs += n_frames * (uint64_t)m->n_states;
+    const uint32_t rx = (uint32_t)((n_frames + 255) / 256);
+    uint32_t ry = std::max(1u, std::min((m->n_states + 7) / 8, (8192 + rx - 1) / rx));
+    ra.states_per_split = (((m->n_states + ry - 1) / ry) + 7u) & ~7u;
+    ry = (m->n_states + ra.states_per_split - 1) / ra.states_per_split;
+    if ((rc = prof_begin(m, m->s_gmm, 0, &ep))) return rc;
+    HIP_TRY(launch_transpose_feats(d_feats, n_frames, m->dim, ldT, m->featsT.p, m->s_gmm));
+    HIP_TRY(launch_gmm_prefilter(pa, m->pf_ks32, m->s_gmm));
+    HIP_TRY(launch_gmm_refine(ra, ry, m->s_gmm));
+    if ((rc = prof_end(m, m->s_gmm, &ep))) return rc;
+  } else if (gmm_kernel == SR_GMM_EXACT || gmm_kernel == SR_GMM_PREFILTER) {
+    // (a model the prefilter cannot take -- sum scoring, > 32 densities per mixture, dim > 47 -- is scored by the
+    // exact kernel: same bits, FP64 VALU speed)
     GmmExactArgs a{};
     a.feats = d_feats; a.n_frames = n_frames; a.dim = m->dim; a.n_states = m->n_states;
     a.dens_off = m->dens_off.p; a.means = m->means.p; a.inv_vars = m->inv_vars.p; a.norm = m->norm.p; a.logw = m->logw.p;
@@ -355,7 +498,7 @@ int sr_model_create(int device, uint32_t dim, uint32_t n_states, const uint32_t*
   sr_model* m = new sr_model();
   m->device = device; m->dim = dim; m->n_states = n_states; m->n_dens = C; m->max_approx = max_approx != 0;
   m->ksteps = ks;
-  m->ld = (n_states + 3u) & ~3u;
+  m->ld = (n_states + 7u) & ~7u;  // 64-byte rows pieces for the kernels that write 8 states per thread
   int rc = SR_OK;
   do {
     hipError_t e;
@@ -377,6 +520,7 @@ int sr_model_create(int device, uint32_t dim, uint32_t n_states, const uint32_t*
       break;
     }
     rc = pack_model(m, dens_off, means, inv_vars, norm, logw);
+    if (rc == SR_OK) rc = pack_prefilter(m, dens_off, means, inv_vars, norm, logw);
     if (rc == SR_OK) {
       std::vector<uint32_t> ident(C);
       std::iota(ident.begin(), ident.end(), 0u);
@@ -870,6 +1014,8 @@ int sr_profile_reset(sr_model* m) {
   for (auto& ep : m->events) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   m->events.clear();
   m->prof = sr_profile{};
+  HIP_TRY(m->pf_counter.ensure(1));
+  HIP_TRY(hipMemset(m->pf_counter.p, 0, sizeof(unsigned long long)));
   return SR_OK;
 }
 
@@ -887,6 +1033,11 @@ int sr_profile_read(sr_model* m, sr_profile* out) {
     (void)hipEventDestroy(ep.b);
   }
   m->events.clear();
+  if (m->pf_counter.p) {
+    unsigned long long n = 0;
+    HIP_TRY(hipMemcpy(&n, m->pf_counter.p, sizeof(n), hipMemcpyDeviceToHost));
+    m->prof.refined_densities = n;
+  }
   *out = m->prof;
   return SR_OK;
 }

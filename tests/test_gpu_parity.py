@@ -35,6 +35,10 @@ def test_golden_scores(name, tmp_path):
     with capi.Model.from_mixset(c.mixset_path, c.dim, c.pooling, c.max_approx) as m:
         exact = m.score_frames(c.feats, capi.GMM_EXACT)
         mfma = m.score_frames(c.feats, capi.GMM_MFMA)
+        pref = m.score_frames(c.feats, capi.GMM_PREFILTER)
+    # bf16 prefilter + FP64 refinement: the same bits as the exact kernel, whatever the model (NaN variances, empty
+    # mixtures, sum mode -> falls through to the exact kernel)
+    assert np.array_equal(pref.view(np.uint64), exact.view(np.uint64))
     if c.max_approx:
         c.check_scores(exact, exact=True)  # bit-identical to MixtureModel::score
     else:
@@ -46,7 +50,10 @@ def test_golden_scores(name, tmp_path):
         _assert_scores_close(mfma.reshape(-1)[c.z["score_idx"]], c.z["score_val"])
 
 
-@pytest.mark.parametrize("kernel", [capi.GMM_EXACT, capi.GMM_MFMA])
+EXACT_KERNELS = (capi.GMM_EXACT, capi.GMM_PREFILTER)
+
+
+@pytest.mark.parametrize("kernel", [capi.GMM_EXACT, capi.GMM_PREFILTER, capi.GMM_MFMA])
 @pytest.mark.parametrize("name", golden_names())
 def test_golden_decode_and_align(name, kernel, tmp_path, oracle_lib):
     c = Case(name, tmp_path)
@@ -63,14 +70,14 @@ def test_golden_decode_and_align(name, kernel, tmp_path, oracle_lib):
         _, (os_, ow, ob) = o.decode(c.feats, traceback=True)
         o.close()
         assert np.array_equal(tbw, ow) and np.array_equal(tbb, ob)
-        if kernel == capi.GMM_EXACT and c.max_approx:
+        if kernel in EXACT_KERNELS and c.max_approx:
             assert np.array_equal(tbs.view(np.uint64), os_.view(np.uint64))
         else:
             _assert_scores_close(tbs, os_)
         if "align_ref" in c.z:
             st, cost = corpus.align([c.z["align_ref"]], c.tdp, sil_state, kernel)
             assert np.array_equal(st, c.z["align_full_states"])
-            if kernel == capi.GMM_EXACT and c.max_approx:
+            if kernel in EXACT_KERNELS and c.max_approx:
                 assert cost[0] == float(c.z["align_full_cost"])
             else:
                 assert abs(cost[0] - float(c.z["align_full_cost"])) <= MFMA_RTOL * max(1.0, abs(float(c.z["align_full_cost"])))
@@ -80,7 +87,7 @@ def test_golden_decode_and_align(name, kernel, tmp_path, oracle_lib):
                                         pruning_threshold=float(c.z[f"align_pruned_thr{i}"]))
                 assert np.array_equal(st, c.z[f"align_pruned_states{i}"])
                 want = float(c.z[f"align_pruned_cost{i}"])
-                if kernel == capi.GMM_EXACT and c.max_approx:
+                if kernel in EXACT_KERNELS and c.max_approx:
                     assert cost[0] == want
                 else:
                     assert abs(cost[0] - want) <= MFMA_RTOL * max(1.0, abs(want))
@@ -125,8 +132,9 @@ def test_batch_vs_oracle(tmp_path, oracle_lib, seed, W, spw, reps, M, D, beam):
         want = o.score_matrix(feats)
         got_exact = corpus.score(capi.GMM_EXACT)
         assert np.array_equal(got_exact.view(np.uint64), want.view(np.uint64))
+        assert np.array_equal(corpus.score(capi.GMM_PREFILTER).view(np.uint64), want.view(np.uint64))
         _assert_scores_close(corpus.score(capi.GMM_MFMA), want)
-        for kernel in (capi.GMM_EXACT, capi.GMM_MFMA):
+        for kernel in (capi.GMM_EXACT, capi.GMM_PREFILTER, capi.GMM_MFMA):
             words, woff = corpus.recognize(lexh, beam, 10.0, kernel)
             for u in range(len(lens)):
                 w = o.decode(feats[int(off[u]):int(off[u + 1])])
@@ -430,3 +438,54 @@ def test_em_iteration_matches_reference_model_file(tmp_path, oracle_lib):
         got_scores = m2.score_frames(z["feats"][:64], capi.GMM_EXACT)
         assert np.array_equal(got_scores.view(np.uint64), want.view(np.uint64))
         _assert_scores_close(m2.score_frames(z["feats"][:64], capi.GMM_MFMA), want)
+
+
+@pytest.mark.parametrize("seed,S,M,D,scale,var_floor,dup", [
+    (901, 61, 32, 39, 1.0, 0.5, False),     # full 32-density mixtures, ragged last group (61 = 15*4 + 1)
+    (902, 40, (1, 32), 39, 1.0, 0.5, False),  # ragged mixture sizes incl. single-density states
+    (903, 24, 16, 39, 30.0, 0.5, False),    # features far from every mean: |b| large, scores ~ 1e4..1e5
+    (904, 24, 16, 39, 1.0, 1e-4, False),    # tiny variances: coefficients ~ 1e4, GEMM-form cancellation
+    (905, 24, 8, 47, 1.0, 0.5, True),       # dim 47 (K = 95, the limit) and duplicated densities (exact ties)
+    (906, 24, 8, 12, 1.0, 0.5, False),      # dim 12 -> one 32-wide k-step
+    (907, 16, 40, 39, 1.0, 0.5, False),     # 40 densities per mixture: not eligible -> exact kernel, same bits
+    (908, 16, 4, 48, 1.0, 0.5, False),      # dim 48: not eligible either
+])
+def test_prefilter_scores_are_bit_identical(tmp_path, oracle_lib, seed, S, M, D, scale, var_floor, dup):
+    """SR_GMM_PREFILTER must return MixtureModel::score's bits: the bf16 stage may only over-select candidates."""
+    rng = np.random.default_rng(seed)
+    nm = M if np.isscalar(M) else rng.integers(M[0], M[1] + 1, size=S)
+    spec = synth.make_mixset(S, nm, D, seed=seed, var_floor=var_floor)
+    if dup:  # second density of every mixture := copy of the first (same accumulators, same weight)
+        for dl in spec.mixtures:
+            if len(dl) > 1:
+                spec.mean_acc[dl[1]] = spec.mean_acc[dl[0]]; spec.var_acc[dl[1]] = spec.var_acc[dl[0]]
+                spec.mean_w[dl[1]] = spec.mean_w[dl[0]]; spec.var_w[dl[1]] = spec.var_w[dl[0]]
+    mp = str(tmp_path / "pf.mix")
+    synth.write_mixset(mp, spec)
+    T = 700  # not a multiple of the 128-frame tile nor of 256
+    feats = (scale * rng.standard_normal((T, D))).astype(np.float32)
+    feats[5] = 0.0
+    feats[6] = 1e-20     # squares underflow in bf16/fp32
+    feats[7, 0] = 250.0  # one dominant component
+    lex = synth.make_lexicon(max(1, (S - 1) // 3), 3, 1, extra_states_last=(S - 1) % 3)
+    o = oracle_lib.Oracle(mp, D, lex)
+    want = o.score_matrix(feats)
+    o.close()
+    with capi.Model.from_mixset(mp, D) as m:
+        got = m.score_frames(feats, capi.GMM_PREFILTER)
+        exact = m.score_frames(feats, capi.GMM_EXACT)
+    assert np.array_equal(exact.view(np.uint64), want.view(np.uint64))
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+def test_prefilter_full_size_matches_exact_kernel(tmp_path):
+    """4000 states x 32 densities (bench model): 3000 frames through both exact paths, compared bit for bit."""
+    lex = synth.make_lexicon(1333, 3, 1)
+    spec = synth.make_mixset(lex.n_states, 32, 39, seed=5)
+    mp = str(tmp_path / "big.mix")
+    synth.write_mixset(mp, spec)
+    feats, _ = synth.make_batch(10, 200, 400, 39, seed=11)
+    with capi.Model.from_mixset(mp, 39) as m:
+        got = m.score_frames(feats, capi.GMM_PREFILTER)
+        exact = m.score_frames(feats, capi.GMM_EXACT)
+    assert np.array_equal(got.view(np.uint64), exact.view(np.uint64))

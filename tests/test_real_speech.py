@@ -59,7 +59,7 @@ def test_oracle_reproduces_reference_on_real_speech(real, oracle_lib, tmp_path, 
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kernel", [1, 0])
+@pytest.mark.parametrize("kernel", [1, 2, 0])
 @pytest.mark.parametrize("pname", ["mixture", "none"])
 def test_gpu_matches_reference_on_real_speech(real, tmp_path, pname, kernel):
     from speechrecognition_amd import capi
@@ -77,7 +77,7 @@ def test_gpu_matches_reference_on_real_speech(real, tmp_path, pname, kernel):
         corpus = m.upload(z["feats"], z["frame_off"])
         if pname == "none":
             got = m.score_frames(z["feats"][off[0]:off[1]], kernel)
-            if kernel == capi.GMM_EXACT:
+            if kernel in (capi.GMM_EXACT, capi.GMM_PREFILTER):
                 assert np.array_equal(got.view(np.uint64), z["none_scores_utt0"].view(np.uint64))
             else:
                 np.testing.assert_allclose(got, z["none_scores_utt0"], rtol=1e-6)
@@ -90,7 +90,7 @@ def test_gpu_matches_reference_on_real_speech(real, tmp_path, pname, kernel):
             assert np.array_equal(st, z[f"{key}_align_full"])
             st2, cost2 = corpus.align(auts, tdp, sil, kernel, pruning_threshold=float(z[f"{key}_athr"]))
             assert np.array_equal(st2, z[f"{key}_align_pruned"])
-            if kernel == capi.GMM_EXACT:
+            if kernel in (capi.GMM_EXACT, capi.GMM_PREFILTER):
                 assert np.array_equal(cost, z[f"{key}_align_full_cost"]) and np.array_equal(cost2, z[f"{key}_align_pruned_cost"])
             else:
                 # GEMM-form scores lose digits where a density has a tiny variance (cancellation ~ mu^2 / sigma^2 * eps,
