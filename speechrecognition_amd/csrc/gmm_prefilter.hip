@@ -2,26 +2,32 @@
 // only OVER-select, followed by an FP64 refinement of the selected densities in the reference's operation order.
 //
 // MixtureModel::min_score (sietill/Mixtures.cpp:696-713) needs, per (frame, state), only the minimum density
-// score.  Kernel P computes every density score of the GEMM form  A[c,:].B[:,t]  (see gmm_mfma.hip) on the
-// bf16 matrix cores with both operands split in two bf16 terms (x ~ x_hi + x_lo, products hi*hi + hi*lo + lo*hi,
-// fp32 accumulation).  Its error is bounded:
-//     |approx - exact| <= (3.03 * 2^-16 + 288 * 2^-24) * sum_k |a_k b_k| <= 6.4e-5 * |a|_2 |b|_2   =: eps / kKappaMargin
-// (bf16 round-to-nearest keeps 8 significant bits per term, a 2-term split 16; the dropped lo*lo product and the
-// two residuals are each <= 2^-16 |ab|; fp32 accumulation of <= 288 terms adds n * 2^-24).  With eps = 1e-4 |a||b|
-// (1.5x margin; |a| = the largest coefficient norm of the state's densities, |b| computed per frame) every
-// density whose approximation lies within 2*eps of the state's smallest approximation -- plus anything that is
-// not a number -- is a candidate; the true arg-min is provably among them.  P writes one 32-bit candidate mask per
-// (frame, state): 1.03-1.06 bits set on average.
+// score.  Kernel P computes every density score in the GEMM form of gmm_mfma.hip,
+//     score(c, t) = konst_c + sum_k a_ck b_kt,   a_c = [1/(2 var); -mu/var],  b_t = [x^2; x],
+// on the bf16 matrix cores: a and b are split in two bf16 terms each (v ~ v_hi + v_lo, round to nearest), the
+// products hi*hi + hi*lo + lo*hi are accumulated in fp32, and konst_c enters through three spare k slots as an
+// exact 3-term bf16 expansion (24 bits) times 1.  Error bound, with u16 = 2^-16, u24 = 2^-24:
+//   * operand splitting: each 2-term split has relative residual <= 2^-17 (hi: 8 bits, lo: 8 more, plus sign), the
+//     dropped lo*lo product is <= 2^-18 |a b|:                      <= 3.03 u16 * sum_k |a_k b_k|
+//   * bf16 x bf16 products are exact in fp32; <= 288 + 3 fp32 additions, each off by u24 of a partial sum that
+//     never exceeds |konst| + sum |a b| (first order):               <= 291 u24 * (|konst_c| + sum_k |a_k b_k|)
+// and sum_k |a_k b_k| <= |a_c|_2 |b_t|_2.  So with  eps = kKappa |a|_2 |b|_2 + kKonst |konst|  (kKappa = 1e-4 against
+// 6.4e-5 needed, kKonst = 3e-5 against 1.74e-5; |a|, |konst| = the largest over the state's densities, rounded
+// up on the host; |b| computed per frame, rounded up) every density whose approximation lies within 2*eps of the
+// state's smallest approximation -- plus anything that is not a number -- is a candidate, and the true arg-min is
+// provably among them.  P writes one 32-bit candidate mask per (frame, state): ~1.01 bits set on average.
 //
 // Kernel R evaluates only the candidates, in FP64, replaying density_score_sse's operation order
 // (Mixtures.cpp:645-690): the minimum over the candidates is the minimum over all densities, bit for bit what
-// MixtureModel::score returns.  P is MFMA/LDS-DMA bound (bf16), R is FP64-VALU/LDS bound with one density per
-// (frame, state) instead of thirty-two.
+// MixtureModel::score returns.  P is MFMA/LDS-DMA bound (bf16), R is FP64-VALU/LDS bound with about one density
+// per (frame, state) instead of thirty-two.
 //
-// Limits of this path: max-approx only, <= 32 densities per mixture, dim <= 47 (K = 2*dim+1 <= 96); otherwise
-// the API falls back to the FP64 MFMA kernel.
+// Limits of this path: max-approx only, <= 32 densities per mixture, dim <= 46 (K = 2*dim + 3 <= 96); any other
+// model is scored by the exact FP64 kernel (same bits).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <algorithm>
 
 #include "kernels.h"
 
@@ -33,7 +39,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 static constexpr int kPWaves = 4;          // waves per workgroup (P)
 static constexpr int kPStageBlocks = 4;    // 16-row model blocks per LDS stage
 static constexpr int kGroupBlocks = 8;     // every 4-state group is padded to 8 blocks = 32 density slots per state
-static constexpr float kKappa = 1.0e-4f;   // eps = kKappa * |a| * |b|   (bound derived above: 6.4e-5)
+static constexpr float kKappa = 1.0e-4f;   // eps = kKappa * |a| * |b| + kKonst * |konst|   (bound derived above)
+static constexpr float kKonst = 3.0e-5f;
 
 __device__ inline uint32_t pack_bf16x2(float lo, float hi) {
   const __bf16 l = (__bf16)lo, h = (__bf16)hi;  // v_cvt_pk_bf16_f32: round to nearest even
@@ -46,7 +53,7 @@ __device__ inline float bf16_round(float v) { return (float)(__bf16)v; }
 // state slot (r >> 2), so that a lane's four accumulator registers (rows 4*(lane>>4) + reg) are four densities of ONE
 // state slot for ONE frame (column lane & 15).
 template <int KS32, int NB>
-__global__ __launch_bounds__(kPWaves * 64) void gmm_prefilter_kernel(GmmPrefilterArgs a) {
+__global__ __launch_bounds__(kPWaves * 64, 3) void gmm_prefilter_kernel(GmmPrefilterArgs a) {
   constexpr int kBlockBytes = KS32 * 2 * 1024;
   constexpr int kStageBytes = kPStageBlocks * kBlockBytes;
   constexpr int kChunksPerStage = kStageBytes / 1024;
@@ -90,18 +97,18 @@ __global__ __launch_bounds__(kPWaves * 64) void gmm_prefilter_kernel(GmmPrefilte
           const uint32_t k = 32u * ks + 8u * g + j, d = k >> 1;
           const double xd = (valid && d < a.dim) ? (double)xr[d < a.dim ? d : 0u] : 0.0;
           double b = (k & 1u) ? xd : xd * xd;  // k = 2d -> x^2 (exact in double), 2d+1 -> x
-          if (valid && k == 2u * a.dim) b = 1.0;
+          n2 += (float)(b * b);
+          if (valid && k >= 2u * a.dim && k < 2u * a.dim + 3u) b = 1.0;  // the three konst slots; not part of |b|
           const float h = bf16_round((float)b);
           hi[j] = h;
           lo[j] = (float)(b - (double)h);
-          n2 += (float)(b * b);
         }
         bh[nb][ks] = make_uint4(pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3]), pack_bf16x2(hi[4], hi[5]), pack_bf16x2(hi[6], hi[7]));
         bl[nb][ks] = make_uint4(pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(lo[4], lo[5]), pack_bf16x2(lo[6], lo[7]));
       }
       n2 += __shfl_xor(n2, 16);
       n2 += __shfl_xor(n2, 32);
-      bnorm[nb] = sqrtf(n2) * 1.0001f;  // rounded up: fp32 summation of <= 96 positive terms
+      bnorm[nb] = sqrtf(n2) * 1.0001f;  // rounded up: fp32 summation of <= 92 positive terms
     }
     __syncthreads();
   }
@@ -119,56 +126,87 @@ __global__ __launch_bounds__(kPWaves * 64) void gmm_prefilter_kernel(GmmPrefilte
     }
   };
 
-  // stage index s covers blocks [g0*8 + 4s, +4): two stages per group
+  // Stage s covers blocks [g0*8 + 4s, +4): two stages per group.  The loop is software-pipelined at k-step
+  // granularity: the two A fragments (hi, lo) of step t+1 are read from LDS before the six MFMAs of step t issue, and at
+  // the last step of a stage the wave joins the barrier for the NEXT stage first, so that the pipeline runs across
+  // stage boundaries and the LDS-DMA of stage s+2 goes into the buffer everybody has just finished reading.
   const uint32_t n_stages = (g1 - g0) * (kGroupBlocks / kPStageBlocks);
+  constexpr int kDmaPerWave = (kChunksPerStage + kPWaves - 1) / kPWaves;
+  static_assert(kChunksPerStage % kPWaves == 0, "every wave issues the same number of LDS-DMA pieces per stage");
+  auto frag = [&](int buf, int j, int ks, int part) -> bf16x8 {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + buf * kStageBytes + j * kBlockBytes + (ks * 2 + part) * 1024 + lane * 16));
+  };
   if (n_stages > 0) issue_stage(g0 * kGroupBlocks, 0);
+  if (n_stages > 1) issue_stage(g0 * kGroupBlocks + kPStageBlocks, 1);
+  if (n_stages > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | kDmaPerWave);  // vmcnt(kDmaPerWave): stage 0 has landed
+  else __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  bf16x8 ah_c, al_c, ah_n, al_n;
+  if (n_stages > 0) { ah_c = frag(0, 0, 0, 0); al_c = frag(0, 0, 0, 1); }
   uint32_t s = 0;
   for (uint32_t grp = g0; grp < g1; grp++) {
     v4f ap[NB][kGroupBlocks];
 #pragma unroll
     for (int half = 0; half < kGroupBlocks / kPStageBlocks; half++, s++) {
       const int buf = s & 1;
-      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's LDS-DMA pieces have landed
-      __syncthreads();
-      if (s + 1 < n_stages) issue_stage(g0 * kGroupBlocks + (s + 1) * kPStageBlocks, buf ^ 1);
 #pragma unroll
       for (int j = 0; j < kPStageBlocks; j++) {
-        const uint4* blk = reinterpret_cast<const uint4*>(lds + buf * kStageBytes + j * kBlockBytes) + lane;
         v4f acc[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) acc[nb] = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < KS32; ks++) {
-          const bf16x8 ah = __builtin_bit_cast(bf16x8, blk[(ks * 2 + 0) * 64]);
-          const bf16x8 al = __builtin_bit_cast(bf16x8, blk[(ks * 2 + 1) * 64]);
-#pragma unroll
-          for (int nb = 0; nb < NB; nb++) {
-            const bf16x8 bhv = __builtin_bit_cast(bf16x8, bh[nb][ks]), blv = __builtin_bit_cast(bf16x8, bl[nb][ks]);
-            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bhv, acc[nb], 0, 0, 0);
-            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, blv, acc[nb], 0, 0, 0);
-            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bhv, acc[nb], 0, 0, 0);
+          if (j == kPStageBlocks - 1 && ks == KS32 - 1) {
+            if (s + 1 < n_stages) {  // workgroup-uniform
+              __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): stage s+1 landed, my reads of stage s returned
+              __syncthreads();
+              if (s + 2 < n_stages) issue_stage(g0 * kGroupBlocks + (s + 2) * kPStageBlocks, buf);
+              ah_n = frag(buf ^ 1, 0, 0, 0);
+              al_n = frag(buf ^ 1, 0, 0, 1);
+            }
+          } else {
+            const int jn = (ks == KS32 - 1) ? j + 1 : j, kn = (ks == KS32 - 1) ? 0 : ks + 1;
+            ah_n = frag(buf, jn, kn, 0);
+            al_n = frag(buf, jn, kn, 1);
           }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int nb = 0; nb < NB; nb++)
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah_c, __builtin_bit_cast(bf16x8, bh[nb][ks]), acc[nb], 0, 0, 0);
+#pragma unroll
+          for (int nb = 0; nb < NB; nb++)
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah_c, __builtin_bit_cast(bf16x8, bl[nb][ks]), acc[nb], 0, 0, 0);
+#pragma unroll
+          for (int nb = 0; nb < NB; nb++)
+            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al_c, __builtin_bit_cast(bf16x8, bh[nb][ks]), acc[nb], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          ah_c = ah_n;
+          al_c = al_n;
         }
 #pragma unroll
         for (int nb = 0; nb < NB; nb++) ap[nb][half * kPStageBlocks + j] = acc[nb];
       }
     }
     // ---- candidate mask of state slot g of this group, for the lane's frame(s) -------------------------------------
-    const float na = a.grp_anorm[4u * grp + g];  // largest |a| over the state's densities (rounded up on the host)
+    // largest |a| and |konst| over the state's densities (rounded up on the host)
+    const float2 nk = reinterpret_cast<const float2*>(a.grp_anorm)[4u * grp + g];
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
       float amin = __builtin_huge_valf();
 #pragma unroll
-      for (int j = 0; j < kGroupBlocks; j++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) amin = fminf(amin, ap[nb][j][i]);  // fminf drops NaNs
-      const float limit = amin + 2.0f * (kKappa * 1.001f) * na * bnorm[nb];
+      for (int j = 0; j < kGroupBlocks; j++) {
+        amin = __builtin_fminf(amin, __builtin_fminf(ap[nb][j][0], ap[nb][j][1]));  // v_min3_f32; fminf drops NaNs
+        amin = __builtin_fminf(amin, __builtin_fminf(ap[nb][j][2], ap[nb][j][3]));
+      }
+      const float limit = amin + 2.0f * ((kKappa * 1.001f) * nk.x * bnorm[nb] + kKonst * nk.y);
+      // mask = 2*mask + !(value > limit), densities in descending order: one compare + one add-with-carry per density.
+      // NaN (bad variance) or an infinite limit: stay candidates.
       uint32_t mask = 0;
 #pragma unroll
-      for (int j = 0; j < kGroupBlocks; j++)
+      for (int j = kGroupBlocks - 1; j >= 0; j--)
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-          mask |= (!(ap[nb][j][i] > limit) ? 1u : 0u) << (4 * j + i);  // NaN (bad variance) or inf limit: stay candidates
+        for (int i = 3; i >= 0; i--)
+          asm("v_cmp_ngt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(ap[nb][j][i]), "v"(limit) : "vcc");
       const uint64_t f = frame0 + (uint64_t)nb * 16 + c;
       if (f < a.n_frames) a.mask[((uint64_t)grp * a.n_frames + f) * 4u + g] = mask;  // 256 contiguous bytes per wave
     }
@@ -188,122 +226,178 @@ hipError_t launch_gmm_prefilter(const GmmPrefilterArgs& a, int ks32, hipStream_t
 int gmm_prefilter_frames_per_tile() { return kPWaves * 2 * 16; }
 
 // ---- kernel R ----------------------------------------------------------------------------------------------
-// One thread per frame (its feature vector converted to FP64 once and kept in registers), a workgroup walks the
-// states of its range.  The FP64 rows of the current state -- [mu_0, 1/var_0, mu_1, 1/var_1, ..., norm, logw], row
-// stride padded to an odd number of 16-byte pieces so that a wave's row gather spreads over all LDS banks -- are
-// brought in by LDS-DMA one state ahead; every lane then reads the rows of ITS candidates.
+// State-stationary: a workgroup owns SPW (8, or 4 for wide features) consecutive states, whose FP64 parameters fill
+// the CU's LDS once (160 KiB for 8 states x 32 densities x 39 dimensions), and streams frames through its threads:
+// one frame per thread at a time, the feature vector converted to FP64 and kept in registers, one 64-byte piece of
+// the output row per frame.  No barrier and no refill inside the frame loop.
+// LDS image per state: planes [mu_0 | 1/var_0 | mu_1 | 1/var_1 | ... | norm | logw] of NS density slots each.  A lane
+// that evaluates density d reads plane[p][d] with ds_read_b64, whose bank pair is d mod 32: lanes on different
+// densities never conflict and lanes on the same density share one broadcast read, whatever the candidates are.
 #pragma clang fp contract(off)
 
-static constexpr int kRThreads = 256;
+static constexpr int kRThreads = 768;   // 3 waves per SIMD; the register budget of 168 holds x in FP64 (78) + pipeline
 static constexpr int kRWaves = kRThreads / 64;
+static constexpr int kRBatch = 4;       // dimensions per software-pipeline stage of the candidate evaluation
 
-template <int DT>  // DT = compile-time feature dimension (0: run-time a.dim, features re-read from featsT)
+template <int DT, int NS, int SPW>  // DT = compile-time feature dimension (0: run-time a.dim, features re-read from featsT)
 __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) {
-  extern __shared__ __attribute__((aligned(1024))) unsigned char panel_raw[];  // [2][panel_bytes]
+  extern __shared__ __attribute__((aligned(1024))) unsigned char panel_raw[];  // [SPW][state_bytes], 1 KB granular
   const uint32_t D = DT ? (uint32_t)DT : a.dim, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const uint64_t f = (uint64_t)blockIdx.x * kRThreads + tid;
-  const bool valid = f < a.n_frames;
-  const uint64_t fc = valid ? f : 0;
-  const uint32_t s0 = blockIdx.y * a.states_per_split;
-  const uint32_t s1 = (s0 + a.states_per_split < a.n_states) ? s0 + a.states_per_split : a.n_states;
-  const uint32_t row_bytes = a.row_stride * 8u;
-  const uint32_t panel_bytes = (a.max_dens * row_bytes + 1023u) & ~1023u;
+  const uint32_t s0 = blockIdx.x * SPW;
+  const uint32_t ns = (s0 + SPW <= a.n_states) ? SPW : a.n_states - s0;  // states of this workgroup
+  const uint32_t state_bytes = (2u * D + 2u) * NS * 8u;
   const uint32_t D2 = D - (D & 1u);
+  const uint64_t f_begin = (uint64_t)blockIdx.y * a.frames_per_split;
+  const uint64_t f_end = (f_begin + a.frames_per_split < a.n_frames) ? f_begin + a.frames_per_split : a.n_frames;
 
-  double x[DT ? DT : 1];
-  if (DT) {
-#pragma unroll
-    for (int k = 0; k < DT; k++) x[k] = (double)a.featsT[(uint64_t)k * a.n_frames_ld + fc];
-  }
-  auto X = [&](uint32_t k) -> double { return DT ? x[DT ? k : 0] : (double)a.featsT[(uint64_t)k * a.n_frames_ld + fc]; };
-
-  // LDS-DMA of one state's rows: 1 KB per wave instruction, round-robin over the waves.  The last piece may run past
-  // the state's rows (into the next state's, or into the tail padding of the buffer): never read back.
-  auto issue_panel = [&](uint32_t st, int buf) {
-    const uint32_t c0 = a.dens_off[st], n = a.dens_off[st + 1] - c0;
-    const uint32_t chunks = __builtin_amdgcn_readfirstlane((n * row_bytes + 1023u) >> 10);
-    const unsigned char* src = reinterpret_cast<const unsigned char*>(a.rows) + (uint64_t)c0 * row_bytes + lane * 16;
-    for (uint32_t ch = wave; ch < chunks; ch += kRWaves) {
-      unsigned char* dst = panel_raw + (size_t)buf * panel_bytes + ch * 1024u;
+  // fill: 1 KB per wave instruction, round-robin over the waves (the last piece may run into the next state's planes
+  // or the buffer's tail slack: never read back)
+  {
+    const uint32_t chunks = (ns * state_bytes + 1023u) >> 10;
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(a.rows) + (uint64_t)s0 * state_bytes + lane * 16;
+    for (uint32_t ch = wave; ch < chunks; ch += kRWaves)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (uint64_t)ch * 1024u),
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    }
-  };
+                                       (__attribute__((address_space(3))) void*)(panel_raw + ch * 1024u), 16, 0, 0);
+  }
+  uint32_t nd[SPW];  // densities per state (wave-uniform)
+#pragma unroll
+  for (int j = 0; j < SPW; j++) nd[j] = (uint32_t)j < ns ? a.dens_off[s0 + j + 1] - a.dens_off[s0 + j] : 0u;
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  __syncthreads();
 
   uint32_t n_eval = 0;
-  if (s0 < s1) issue_panel(s0, 0);
-  // eight states per pass: a thread then owns one 64-byte aligned piece of its output row (ld and the split size
-  // are multiples of 8) instead of scattering 8-byte stores that each cost a 64-byte HBM write
-  for (uint32_t s8 = s0; s8 < s1; s8 += 8) {
-    double res[8];
-    uint32_t mk[8];
+  for (uint64_t f = f_begin + tid; f < f_end; f += kRThreads) {
+    double x[DT ? DT : 1];
+    if (DT) {
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const uint4 v = (s8 + 4 * h < s1) ? reinterpret_cast<const uint4*>(a.mask)[(uint64_t)((s8 >> 2) + h) * a.n_frames + fc]
-                                        : make_uint4(0, 0, 0, 0);
-      mk[4 * h] = v.x; mk[4 * h + 1] = v.y; mk[4 * h + 2] = v.z; mk[4 * h + 3] = v.w;
+      for (int k = 0; k < DT; k++) x[k] = (double)a.featsT[(uint64_t)k * a.n_frames_ld + f];
     }
+    auto X = [&](uint32_t k) -> double { return DT ? x[DT ? k : 0] : (double)a.featsT[(uint64_t)k * a.n_frames_ld + f]; };
+    // score of the density whose plane column starts at LDS address `col0`, in density_score_sse's operation order
+    auto evaluate = [&](const unsigned char* col0) __attribute__((always_inline)) -> double {
+      // volatile: keeps every read a ds_read_b64 (256 B/clk, 64 banks); merged into ds_read2_b64 they would run at
+      // half rate on 32 banks, where densities d and d + 16 collide
+      const volatile __attribute__((address_space(3))) double* col =
+          (const volatile __attribute__((address_space(3))) double*)col0;  // col[plane * NS]
+      double l0 = 0.0, l1 = 0.0, dist, score;
+      if (DT) {
+        // software pipeline over batches of kRBatch dimensions: the reads of batch b+1 are issued before the
+        // arithmetic of batch b (volatile reads are not moved by the compiler, hence the explicit fences)
+        constexpr int NB_ = (DT + 1 + kRBatch - 1) / kRBatch;  // plane pairs 0..DT-1 = dimensions, pair DT = (norm, logw)
+        double pm[2][kRBatch], pv[2][kRBatch];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const uint32_t st = s8 + j;
-      res[j] = 0.0;
-      if (st < s1) {  // workgroup-uniform
-        const int buf = (st - s0) & 1;
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of panel `buf` have landed
-        __syncthreads();                     // ... and everybody's; panel buf^1 is no longer read
-        if (st + 1 < s1) issue_panel(st + 1, buf ^ 1);
-        const unsigned char* p = panel_raw + (size_t)buf * panel_bytes;
-        const uint32_t n = a.dens_off[st + 1] - a.dens_off[st];
-        uint32_t mask = mk[j];
+        for (int i = 0; i < kRBatch; i++)
+          if (i <= DT) { pm[0][i] = col[(2 * i) * NS]; pv[0][i] = col[(2 * i + 1) * NS]; }
+#pragma unroll
+        for (int b = 0; b < NB_; b++) {
+          const int cur = b & 1;
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < kRBatch; i++) {
+            const int k = (b + 1) * kRBatch + i;
+            if (k <= DT) { pm[cur ^ 1][i] = col[(2 * k) * NS]; pv[cur ^ 1][i] = col[(2 * k + 1) * NS]; }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < kRBatch; i++) {
+            const int k = b * kRBatch + i;
+            if (k < (int)(DT - (DT & 1))) {
+              double u = x[DT ? k : 0] - pm[cur][i];
+              u = u * u;
+              u = u * pv[cur][i];
+              if (k & 1) l1 = l1 + u; else l0 = l0 + u;
+            } else if (k == DT - 1) {  // odd dimension count: scalar tail (Mixtures.cpp:680-683)
+              dist = l0 + l1;
+              const double t = x[DT ? k : 0] - pm[cur][i];
+              dist += t * t * pv[cur][i];
+            } else if (k == DT) {
+              if (!(DT & 1)) dist = l0 + l1;
+              score = pm[cur][i] + dist / 2;
+              score -= pv[cur][i];
+            }
+          }
+          // pins this batch's arithmetic between the read groups (ordered against the volatile reads); without it
+          // the arithmetic sinks below all 80 reads and their 160 destination registers spill
+          asm volatile("" : "+v"(l0), "+v"(l1));
+        }
+      } else {
+        for (uint32_t k = 0; k < D2; k += 2) {
+          double u = X(k) - col[(2 * k) * NS];
+          u = u * u;
+          u = u * col[(2 * k + 1) * NS];
+          l0 = l0 + u;
+          double v = X(k + 1) - col[(2 * k + 2) * NS];
+          v = v * v;
+          v = v * col[(2 * k + 3) * NS];
+          l1 = l1 + v;
+        }
+        dist = l0 + l1;
+        if (D & 1u) {
+          const double t = X(D - 1) - col[(2 * (D - 1)) * NS];
+          dist += t * t * col[(2 * (D - 1) + 1) * NS];
+        }
+        score = col[(2 * D) * NS] + dist / 2;
+        score -= col[(2 * D + 1) * NS];
+      }
+      return score;
+    };
+
+    // Phase 1: the first candidate of every state -- one evaluation per state in every lane, no divergence.
+    double res[SPW];
+    uint32_t rem[SPW];  // candidates left after the first
+#pragma unroll
+    for (int h = 0; h < SPW / 4; h++) {
+      const uint4 v = reinterpret_cast<const uint4*>(a.mask)[(uint64_t)((s0 >> 2) + h) * a.n_frames + f];
+      const uint32_t mk[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int jj = 0; jj < 4; jj++) {
+        const int j = 4 * h + jj;
+        const uint32_t n = nd[j];
+        uint32_t mask = mk[jj];
         mask &= n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);  // padding slots of the prefilter are not densities
         n_eval += __builtin_popcount(mask);
-        double best = 1e10;  // min_score seed (Mixtures.cpp:699)
-        while (mask) {       // ascending density order, strict <: same minimum as the reference's full scan
-          const uint32_t d = __builtin_ctz(mask);
-          mask &= mask - 1;
-          const double2* row = reinterpret_cast<const double2*>(p + d * row_bytes);  // row[k] = (mu_k, 1/var_k)
-          double l0 = 0.0, l1 = 0.0;
-#pragma unroll
-          for (uint32_t k = 0; k < D2; k += 2) {
-            const double2 r0 = row[k], r1 = row[k + 1];
-            double u = X(k) - r0.x;
-            u = u * u;
-            u = u * r0.y;
-            l0 = l0 + u;
-            double v = X(k + 1) - r1.x;
-            v = v * v;
-            v = v * r1.y;
-            l1 = l1 + v;
-          }
-          double dist = l0 + l1;
-          if (D & 1u) {
-            const double2 r = row[D - 1];
-            const double t = X(D - 1) - r.x;
-            dist += t * t * r.y;
-          }
-          const double2 nl = row[D];  // (norm, logw)
-          double score = nl.x + dist / 2;
-          score -= nl.y;
-          if (score < best) best = score;
+        res[j] = 1e10;  // min_score seed (Mixtures.cpp:699)
+        if (mask) {     // (empty only for a state without densities)
+          const double score = evaluate(panel_raw + (size_t)j * state_bytes + __builtin_ctz(mask) * 8u);
+          if (score < res[j]) res[j] = score;
         }
-        res[j] = best;
+        rem[j] = mask & (mask - 1);
       }
     }
-    if (valid) {
-      double* o = a.out + f * a.ld + s8;
-      if (s8 + 8 <= s1) {
+    // Phase 2: the few lanes that have further candidates (about 1 % of the (frame, state) pairs) work them off
+    // together, each on its own (state, density); different states' planes keep the bank pair d mod 32.  The minimum
+    // does not depend on the order (strict <, NaN never wins: as in the reference's ascending scan).
+    for (;;) {
+      uint32_t any = 0;
 #pragma unroll
-        for (int j = 0; j < 8; j += 2) *reinterpret_cast<double2*>(o + j) = make_double2(res[j], res[j + 1]);
-      } else {
+      for (int j = 0; j < SPW; j++) any |= rem[j];
+      if (!any) break;
+      int jsel = 0;
+      uint32_t msel = 0;
 #pragma unroll
-        for (int j = 0; j < 8; j++)
-          if (s8 + j < s1) o[j] = res[j];
-      }
+      for (int j = SPW - 1; j >= 0; j--)
+        if (rem[j]) { jsel = j; msel = rem[j]; }
+      const uint32_t d = __builtin_ctz(msel);
+#pragma unroll
+      for (int j = 0; j < SPW; j++)
+        if (j == jsel) rem[j] = msel & (msel - 1);
+      const double score = evaluate(panel_raw + (size_t)jsel * state_bytes + d * 8u);
+#pragma unroll
+      for (int j = 0; j < SPW; j++)
+        if (j == jsel && score < res[j]) res[j] = score;
+    }
+    double* o = a.out + f * a.ld + s0;
+    if (ns == SPW) {  // ld is a multiple of 8: 64-byte (32-byte for SPW = 4) aligned pieces
+#pragma unroll
+      for (int j = 0; j < SPW; j += 2) *reinterpret_cast<double2*>(o + j) = make_double2(res[j], res[j + 1]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < SPW; j++)
+        if ((uint32_t)j < ns) o[j] = res[j];
     }
   }
   if (a.n_refined) {
-    if (!valid) n_eval = 0;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) n_eval += __shfl_xor(n_eval, o);
     if (lane == 0) atomicAdd(a.n_refined, (unsigned long long)n_eval);
@@ -333,10 +427,21 @@ hipError_t launch_transpose_feats(const float* feats, uint64_t n_frames, uint32_
   return hipGetLastError();
 }
 
-hipError_t launch_gmm_refine(const GmmRefineArgs& a, uint32_t n_splits, hipStream_t stream) {
-  if (a.n_frames == 0) return hipSuccess;
-  const size_t smem = 2 * (((size_t)a.max_dens * a.row_stride * 8 + 1023) & ~(size_t)1023);
-  const dim3 grid((unsigned)((a.n_frames + kRThreads - 1) / kRThreads), n_splits), block(kRThreads);
+int gmm_refine_slots(uint32_t max_dens) { return max_dens <= 8 ? 8 : max_dens <= 16 ? 16 : 32; }
+
+template <int NS, int SPW>
+static hipError_t launch_refine_ns(const GmmRefineArgs& a0, hipStream_t stream) {
+  GmmRefineArgs a = a0;
+  const size_t state_bytes = (size_t)(2 * a.dim + 2) * NS * 8;
+  const size_t smem = (SPW * state_bytes + 1023) & ~(size_t)1023;
+  const uint32_t n_sgroups = (a.n_states + SPW - 1) / SPW;
+  // two rounds of workgroups over the 256 CUs at least (one workgroup per CU when it takes the whole LDS), without
+  // cutting the frame range below one pass of the threads
+  uint64_t splits = std::max<uint64_t>(1, (512 + n_sgroups - 1) / n_sgroups);
+  splits = std::min<uint64_t>(splits, (a.n_frames + kRThreads - 1) / kRThreads);
+  a.frames_per_split = (a.n_frames + splits - 1) / splits;
+  splits = (a.n_frames + a.frames_per_split - 1) / a.frames_per_split;
+  const dim3 grid(n_sgroups, (unsigned)splits), block(kRThreads);
   auto go = [&](auto kernel) {
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
@@ -344,9 +449,21 @@ hipError_t launch_gmm_refine(const GmmRefineArgs& a, uint32_t n_splits, hipStrea
     return hipGetLastError();
   };
   switch (a.dim) {
-    case 39: return go(gmm_refine_kernel<39>);
-    case 25: return go(gmm_refine_kernel<25>);
-    default: return go(gmm_refine_kernel<0>);
+    case 39: return go(gmm_refine_kernel<39, NS, SPW>);
+    case 25: return go(gmm_refine_kernel<25, NS, SPW>);
+    default: return go(gmm_refine_kernel<0, NS, SPW>);
+  }
+}
+
+hipError_t launch_gmm_refine(const GmmRefineArgs& a, hipStream_t stream) {
+  if (a.n_frames == 0) return hipSuccess;
+  // 8 states per workgroup when their parameters fit the 160 KiB of LDS (dim <= 39 at 32 slots), else 4
+  const bool eight = (size_t)(2 * a.dim + 2) * a.n_slots * 8 * 8 <= 160 * 1024;
+  switch (a.n_slots) {
+    case 8: return launch_refine_ns<8, 8>(a, stream);
+    case 16: return launch_refine_ns<16, 8>(a, stream);
+    case 32: return eight ? launch_refine_ns<32, 8>(a, stream) : launch_refine_ns<32, 4>(a, stream);
+    default: return hipErrorInvalidValue;
   }
 }
 

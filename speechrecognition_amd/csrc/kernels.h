@@ -45,7 +45,7 @@ struct GmmPrefilterArgs {
   uint64_t n_frames;
   uint32_t dim;
   const unsigned char* apack;   // [n_groups*8 blocks][KS32][hi/lo][64 lanes][8 bf16]
-  const float* grp_anorm;       // [n_groups*4] largest coefficient norm of the state in that slot
+  const float* grp_anorm;       // [n_groups*4][2] largest |a|_2 and |konst| over the densities of the state in that slot
   const uint32_t* split_begin;  // [ny+1] group ranges
   uint32_t* mask;               // [group][frame][4 state slots] candidate densities of (frame, state)
   uint32_t nx, ny;
@@ -55,17 +55,18 @@ struct GmmRefineArgs {
   uint64_t n_frames, n_frames_ld;
   uint32_t dim, n_states, max_dens;
   const uint32_t* dens_off;
-  const double* rows;           // [C][row_stride]: mu_0, 1/var_0, ..., mu_{D-1}, 1/var_{D-1}, norm, logw, padding;
-                                // 1 KB of slack after the last row
-  uint32_t row_stride;          // doubles; row_stride/2 odd and >= dim + 1
+  const double* rows;           // [state][2*dim + 2 planes][n_slots]: mu_0, 1/var_0, ..., norm, logw per density slot;
+                                // 1 KB of slack after the last state
+  uint32_t n_slots;             // gmm_refine_slots(max_dens): 8, 16 or 32
   const uint32_t* mask;         // as written by the prefilter
   double* out; uint32_t ld;
-  uint32_t states_per_split;
+  uint64_t frames_per_split;    // set by the launcher
   unsigned long long* n_refined;  // optional: += densities evaluated (profiling)
 };
 hipError_t launch_gmm_prefilter(const GmmPrefilterArgs& a, int ks32, hipStream_t stream);
 int gmm_prefilter_frames_per_tile();
-hipError_t launch_gmm_refine(const GmmRefineArgs& a, uint32_t n_splits, hipStream_t stream);
+int gmm_refine_slots(uint32_t max_dens);
+hipError_t launch_gmm_refine(const GmmRefineArgs& a, hipStream_t stream);
 hipError_t launch_transpose_feats(const float* feats, uint64_t n_frames, uint32_t dim, uint64_t ldT, float* out, hipStream_t stream);
 
 // ---- beam Viterbi decoder (viterbi_decode.hip) ---------------------------------------------------

@@ -93,7 +93,7 @@ struct sr_model {
   uint32_t split_ny = 0;
   // bf16 prefilter + FP64 refinement (gmm_prefilter.hip); pf_ks32 == 0: model not eligible
   int pf_ks32 = 0;
-  uint32_t pf_groups = 0, pf_ny = 0, max_dens = 0, pf_row_stride = 0;
+  uint32_t pf_groups = 0, pf_ny = 0, max_dens = 0, pf_slots = 0;
   DevBuf<unsigned char> pf_apack;
   DevBuf<float> pf_anorm, featsT;
   DevBuf<uint32_t> pf_split, pf_mask;
@@ -245,28 +245,30 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
   uint32_t mx = 0;
   for (uint32_t s = 0; s < S; s++) mx = std::max(mx, dens_off[s + 1] - dens_off[s]);
   m->max_dens = std::max(1u, mx);
-  // FP64 rows for the refinement: [density][mu_0, 1/var_0, ..., norm, logw, padding]; an odd number of 16-byte pieces
-  // per row spreads a wave's row gather over all LDS banks; 1 KB of slack for the LDS-DMA's last piece
+  m->pf_ks32 = 0;
+  if (!m->max_approx || mx > 32 || 2 * D + 3 > 96) return SR_OK;  // not eligible: callers get the exact kernel
+  // FP64 planes for the refinement: [state][mu_0 | 1/var_0 | ... | norm | logw][density slot]; 1 KB of slack for the
+  // LDS-DMA's last piece
   {
-    uint32_t q = D + 1;
-    if ((q & 1u) == 0) q++;
-    m->pf_row_stride = 2 * q;
-    std::vector<double> rows((size_t)m->n_dens * m->pf_row_stride + 128, 0.0);
-    for (size_t c = 0; c < (size_t)m->n_dens; c++) {
-      double* r = rows.data() + c * m->pf_row_stride;
-      for (uint32_t d = 0; d < D; d++) { r[2 * d] = means[c * D + d]; r[2 * d + 1] = inv_vars[c * D + d]; }
-      r[2 * D] = norm[c];
-      r[2 * D + 1] = logw[c];
+    const uint32_t NS = (uint32_t)gmm_refine_slots(m->max_dens), planes = 2 * D + 2;
+    m->pf_slots = NS;
+    std::vector<double> rows((size_t)S * planes * NS + 128, 0.0);
+    for (uint32_t st = 0; st < S; st++) {
+      double* r = rows.data() + (size_t)st * planes * NS;
+      for (uint32_t i = 0; i < dens_off[st + 1] - dens_off[st]; i++) {
+        const size_t c = (size_t)dens_off[st] + i;
+        for (uint32_t d = 0; d < D; d++) { r[(2 * d) * NS + i] = means[c * D + d]; r[(2 * d + 1) * NS + i] = inv_vars[c * D + d]; }
+        r[(2 * D) * NS + i] = norm[c];
+        r[(2 * D + 1) * NS + i] = logw[c];
+      }
     }
     HIP_TRY(m->pf_rows.upload(rows.data(), rows.size()));
   }
-  m->pf_ks32 = 0;
-  if (!m->max_approx || mx > 32 || 2 * D + 1 > 96) return SR_OK;  // not eligible: callers get the exact kernel
-  const int KS = (int)((2 * D + 1 + 31) / 32);
+  const int KS = (int)((2 * D + 3 + 31) / 32);
   const uint32_t n_groups = (S + 3) / 4;
   const size_t blk_bytes = (size_t)KS * 2 * 1024;
   std::vector<uint16_t> ap((size_t)n_groups * 8 * blk_bytes / 2, 0);
-  std::vector<float> anorm(4 * (size_t)n_groups, 0.0f);
+  std::vector<float> anorm(8 * (size_t)n_groups, 0.0f);  // (|a|, |konst|) per state slot
   std::vector<double> arow(32 * (size_t)KS);
   for (uint32_t q = 0; q < n_groups; q++) {
     for (uint32_t j = 0; j < 8; j++) {
@@ -275,6 +277,8 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
         const uint32_t g = r >> 2, st = 4 * q + g, i = 4 * j + (r & 3);
         const bool real = st < S && i < dens_off[st + 1] - dens_off[st];
         std::fill(arow.begin(), arow.end(), 0.0);
+        const float finf = std::numeric_limits<float>::infinity();
+        double konst = 3.0e38;  // padding slot: never below a real score, masked off again by the refinement
         if (real) {
           const size_t c = (size_t)dens_off[st] + i;
           double q2 = 0.0, n2 = 0.0;
@@ -284,18 +288,27 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
             arow[2 * d + 1] = -mu * iv;
             q2 += mu * mu * iv;
           }
-          arow[2 * D] = norm[c] - logw[c] + 0.5 * q2;
-          for (uint32_t k = 0; k <= 2 * D; k++) n2 += arow[k] * arow[k];
-          const float na = std::nextafter((float)(std::sqrt(n2) * (1.0 + 1e-6)), std::numeric_limits<float>::infinity());
-          if (!(na <= anorm[4 * q + g])) anorm[4 * q + g] = na;  // NaN sticks: everything of that state stays a candidate
-        } else {
-          arow[2 * D] = 3.0e38;  // padding slot: never below a real score, masked off again by the refinement
+          konst = norm[c] - logw[c] + 0.5 * q2;
+          for (uint32_t k = 0; k < 2 * D; k++) n2 += arow[k] * arow[k];
+          const float na = std::nextafter((float)(std::sqrt(n2) * (1.0 + 1e-6)), finf);
+          const float nk = std::nextafter((float)(std::fabs(konst) * (1.0 + 1e-6)), finf);
+          // NaN sticks: everything of that state then stays a candidate
+          if (!(na <= anorm[2 * (4 * q + g)])) anorm[2 * (4 * q + g)] = na;
+          if (!(nk <= anorm[2 * (4 * q + g) + 1])) anorm[2 * (4 * q + g) + 1] = nk;
+        }
+        // konst = c1 + c2 + c3 in bf16 (24 bits), multiplied by 1 in three spare k slots: exact products
+        double rest = konst;
+        for (uint32_t t = 0; t < 3; t++) {
+          const float c = bf16_to_float(bf16_rne((float)rest));
+          arow[2 * D + t] = c;
+          rest -= (double)c;
         }
         for (int ks = 0; ks < KS; ks++)
           for (uint32_t kk = 0; kk < 32; kk++) {
-            const double v = arow[32 * ks + kk];
+            const uint32_t k = 32 * ks + kk;
+            const double v = arow[k];
             const uint16_t hi = bf16_rne((float)v);
-            const uint16_t lo = real ? bf16_rne((float)(v - (double)bf16_to_float(hi))) : (uint16_t)0;
+            const uint16_t lo = (real && k < 2 * D) ? bf16_rne((float)(v - (double)bf16_to_float(hi))) : (uint16_t)0;
             const uint32_t lane = r + 16 * (kk >> 3), e = kk & 7;
             const size_t base = (b * blk_bytes) / 2 + (size_t)ks * 1024 + (size_t)lane * 8 + e;
             ap[base] = hi;
@@ -316,6 +329,7 @@ int set_prefilter_splits(sr_model* m, uint32_t nx) {
   const uint32_t target_wgs = 16 * 768;
   uint32_t ny = (target_wgs + nx - 1) / std::max(1u, nx);
   ny = std::max(1u, std::min(ny, std::max(1u, m->pf_groups / 8)));
+  if (const char* e = getenv("SRGPU_PF_NY")) ny = std::max(1u, std::min((uint32_t)atoi(e), m->pf_groups));
   if (ny >= 8) ny &= ~7u;
   if (ny == m->pf_ny) return SR_OK;
   std::vector<uint32_t> sb(ny + 1);
@@ -389,25 +403,21 @@ int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm
     if (rc) return rc;
     const uint64_t ldT = (n_frames + 63) & ~(uint64_t)63;
     HIP_TRY(m->featsT.ensure((size_t)ldT * m->dim));
-    HIP_TRY(m->pf_mask.ensure((size_t)m->pf_groups * n_frames * 4));
+    HIP_TRY(m->pf_mask.ensure((size_t)((m->pf_groups + 1u) & ~1u) * n_frames * 4));  // the refinement reads group pairs
     GmmPrefilterArgs pa{};
     pa.feats = d_feats; pa.n_frames = n_frames; pa.dim = m->dim;
     pa.apack = m->pf_apack.p; pa.grp_anorm = m->pf_anorm.p; pa.split_begin = m->pf_split.p;
     pa.mask = m->pf_mask.p; pa.nx = nx; pa.ny = m->pf_ny;
     GmmRefineArgs ra{};
     ra.featsT = m->featsT.p; ra.n_frames = n_frames; ra.n_frames_ld = ldT; ra.dim = m->dim; ra.n_states = m->n_states;
-    ra.max_dens = m->max_dens; ra.dens_off = m->dens_off.p; ra.rows = m->pf_rows.p; ra.row_stride = m->pf_row_stride;
+    ra.max_dens = m->max_dens; ra.dens_off = m->dens_off.p; ra.rows = m->pf_rows.p; ra.n_slots = m->pf_slots;
     ra.mask = m->pf_mask.p; ra.out = d_out; ra.ld = m->ld;
     ra.n_refined = m->profiling ? m->pf_counter.p : nullptr;
     if (m->profiling) m->prof.refined_pairs += n_frames * (uint64_t)m->n_states;
-    const uint32_t rx = (uint32_t)((n_frames + 255) / 256);
-    uint32_t ry = std::max(1u, std::min((m->n_states + 7) / 8, (8192 + rx - 1) / rx));
-    ra.states_per_split = (((m->n_states + ry - 1) / ry) + 7u) & ~7u;
-    ry = (m->n_states + ra.states_per_split - 1) / ra.states_per_split;
     if ((rc = prof_begin(m, m->s_gmm, 0, &ep))) return rc;
     HIP_TRY(launch_transpose_feats(d_feats, n_frames, m->dim, ldT, m->featsT.p, m->s_gmm));
     HIP_TRY(launch_gmm_prefilter(pa, m->pf_ks32, m->s_gmm));
-    HIP_TRY(launch_gmm_refine(ra, ry, m->s_gmm));
+    HIP_TRY(launch_gmm_refine(ra, m->s_gmm));
     if ((rc = prof_end(m, m->s_gmm, &ep))) return rc;
   } else if (gmm_kernel == SR_GMM_EXACT || gmm_kernel == SR_GMM_PREFILTER) {
     // (a model the prefilter cannot take -- sum scoring, > 32 densities per mixture, dim > 47 -- is scored by the

@@ -445,10 +445,10 @@ def test_em_iteration_matches_reference_model_file(tmp_path, oracle_lib):
     (902, 40, (1, 32), 39, 1.0, 0.5, False),  # ragged mixture sizes incl. single-density states
     (903, 24, 16, 39, 30.0, 0.5, False),    # features far from every mean: |b| large, scores ~ 1e4..1e5
     (904, 24, 16, 39, 1.0, 1e-4, False),    # tiny variances: coefficients ~ 1e4, GEMM-form cancellation
-    (905, 24, 8, 47, 1.0, 0.5, True),       # dim 47 (K = 95, the limit) and duplicated densities (exact ties)
+    (905, 24, 8, 46, 1.0, 0.5, True),       # dim 46 (K = 95, the limit) and duplicated densities (exact ties)
     (906, 24, 8, 12, 1.0, 0.5, False),      # dim 12 -> one 32-wide k-step
     (907, 16, 40, 39, 1.0, 0.5, False),     # 40 densities per mixture: not eligible -> exact kernel, same bits
-    (908, 16, 4, 48, 1.0, 0.5, False),      # dim 48: not eligible either
+    (908, 16, 4, 47, 1.0, 0.5, False),      # dim 47: not eligible either
 ])
 def test_prefilter_scores_are_bit_identical(tmp_path, oracle_lib, seed, S, M, D, scale, var_floor, dup):
     """SR_GMM_PREFILTER must return MixtureModel::score's bits: the bf16 stage may only over-select candidates."""
