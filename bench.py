@@ -44,7 +44,9 @@ def parse():
     ap.add_argument("--words", type=int, default=1333, help="three-state words (states = 1 + 3*words)")
     ap.add_argument("--mix", type=int, default=32)
     ap.add_argument("--beam", type=float, default=200.0)
-    ap.add_argument("--kernel", choices=["mfma", "exact", "prefilter"], default="mfma")
+    ap.add_argument("--kernel", choices=["mfma", "exact", "prefilter"], default="prefilter",
+                    help="GMM scoring path: prefilter (fp16 MFMA candidate pass + exact FP64 refinement, bit-exact scores), "
+                         "mfma (dense FP64 MFMA, ~1e-15), exact (dense FP64 VALU, bit-exact)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals "
                     "where several ranks share one GPU)")
@@ -140,19 +142,7 @@ def main():
                 "frames_per_gpu_rank0": n_frames, "words": lex.n_words, "trellis_positions": int(word_off[-1]),
                 "gmm_kernel": args.kernel, "parallelism": f"utterance-shard x{world}, no collective",
             },
-            "roofline": {
-                "kernel": "gmm_mfma_kernel" if args.kernel == "mfma" else "gmm_exact_kernel",
-                "bound": "mfma",
-                "achieved": achieved,
-                "peak": FP64_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                "traffic": pmc_traffic(args, n_frames),
-                "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, KB units, separate rocprofv3 --pmc passes)",
-                "launches": prof["gmm_launches"],
-                "avg_launch_ms": prof["gmm_ms"] / max(1, prof["gmm_launches"]),
-                "flops_per_frame": 4.0 * D * S * args.mix,
-            },
+            "roofline": gmm_roofline(args, prof, n_frames, D, S),
             "search": {
                 "kernel": "decode_kernel",
                 "bound": "hbm",
@@ -162,9 +152,8 @@ def main():
             },
             "recognised_words_rank0": int(woff[-1]),
         }
-        if prof.get("refined_pairs"):
-            out["prefilter"] = {"densities_refined_per_pair": prof["refined_densities"] / prof["refined_pairs"],
-                                "of": args.mix}
+        if args.kernel == "prefilter":
+            out.update(prefilter_report(args, prof, n_frames, D, S))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, mixset_path, lex, tdp, wp, feats, frame_off, words, woff)
         print(json.dumps(out))
@@ -178,7 +167,58 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(args, n_frames):
+FP64_VALU_UNFUSED_PEAK = 39.3  # Tflop/s: one v_add_f64 / v_mul_f64 per lane and cycle (profiles/r1_fp64_rate_microbench.txt: 36.8)
+F16_MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA (MI355X_MICROARCH.md); ~1250-1480 sustained on random data (DVFS)
+
+
+def gmm_roofline(args, prof, n_frames, D, S):
+    """Roofline of the dominant kernel of the step.
+
+    mfma / exact: the dense scoring kernel, SURVEY 8(d): 4*D*C flops per frame against the FP64 matrix peak.
+    prefilter:    the FP64 refinement kernel dominates.  Its algorithmic work is ONE exact density evaluation per
+                  (frame, state) -- 4*D unfused flops, the reference's operation order forbids FMA -- against the
+                  FP64 vector pipe (bound "valu": the contract's enum has no name for it; the dense-FP64-equivalent
+                  rate of the whole step is under "gmm_step").
+    """
+    launches = max(1, prof["gmm_launches"])
+    if args.kernel == "prefilter":
+        ms = prof["refine_ms"] / launches
+        flops = 4.0 * D * S * n_frames
+        achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        return {"kernel": "gmm_refine_kernel", "bound": "valu", "achieved": achieved, "peak": FP64_VALU_UNFUSED_PEAK,
+                "unit": "TFLOP/s", "frac": achieved / FP64_VALU_UNFUSED_PEAK, "traffic": pmc_traffic(args, n_frames, "gmm_refine_kernel"),
+                "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, KB units, separate rocprofv3 --pmc passes)",
+                "launches": prof["gmm_launches"], "avg_launch_ms": ms,
+                "flops_per_frame": 4.0 * D * S, "dtype": "f64 unfused add/mul"}
+    gmm_s = prof["gmm_ms"] * 1e-3
+    achieved = prof["gmm_flops"] / gmm_s / 1e12 if gmm_s > 0 else 0.0
+    return {"kernel": "gmm_mfma_kernel" if args.kernel == "mfma" else "gmm_exact_kernel", "bound": "mfma",
+            "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+            "traffic": pmc_traffic(args, n_frames, "gmm_mfma_kernel") if args.kernel == "mfma" else None,
+            "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, KB units, separate rocprofv3 --pmc passes)",
+            "launches": prof["gmm_launches"], "avg_launch_ms": prof["gmm_ms"] / launches,
+            "flops_per_frame": 4.0 * D * S * args.mix}
+
+
+def prefilter_report(args, prof, n_frames, D, S):
+    launches = max(1, prof["gmm_launches"])
+    p_ms, g_ms = prof["prefilter_ms"] / launches, prof["gmm_ms"] / launches
+    k = 32 * ((2 * D + 3 + 31) // 32)
+    p_flops = 2.0 * k * (32 * 4 * ((S + 3) // 4)) * n_frames  # one fp16 product, states padded to 32 density slots
+    dense = 4.0 * D * S * args.mix * n_frames
+    return {
+        "roofline_prefilter": {"kernel": "gmm_prefilter16_kernel", "bound": "mfma", "achieved": p_flops / (p_ms * 1e-3) / 1e12,
+                               "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": p_flops / (p_ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS,
+                               "avg_launch_ms": p_ms, "dtype": "f16 x f16 -> f32", "includes": "feature transpose (0.04 ms)"},
+        "gmm_step": {"ms": g_ms, "dense_fp64_flops": dense, "dense_fp64_equiv_tflops": dense / (g_ms * 1e-3) / 1e12,
+                     "vs_fp64_mfma_peak": dense / (g_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+                     "densities_refined_per_pair": prof["refined_densities"] / max(1, prof["refined_pairs"]), "of": args.mix,
+                     "note": "scores bit-identical to the reference; SURVEY 8(d)'s 4*D*C flops per frame are not executed in "
+                             "FP64 any more, so the dense-equivalent rate exceeds the FP64 peak"},
+    }
+
+
+def pmc_traffic(args, n_frames, kernel="gmm_mfma_kernel"):
     """HBM bytes per GMM launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the
     timed process); only reported when they were taken on this very workload, else null."""
     path = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")
@@ -186,9 +226,9 @@ def pmc_traffic(args, n_frames):
         z = json.load(open(path))
     except (OSError, ValueError):
         return None
-    if args.kernel != "mfma" or z.get("workload_frames_per_launch") != n_frames or args.words != 1333 or args.mix != 32:
+    if z.get("workload_frames_per_launch") != n_frames or args.words != 1333 or args.mix != 32 or kernel not in z:
         return None
-    return z["gmm_mfma_kernel"]["hbm_bytes_per_launch_corrected"]
+    return z[kernel]["hbm_bytes_per_launch_corrected"]
 
 
 def usable_cores():

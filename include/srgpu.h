@@ -177,6 +177,8 @@ typedef struct {
   uint64_t frames;      /* frames processed */
   uint64_t refined_pairs;      /* SR_GMM_PREFILTER: (frame, state) pairs scored ... */
   uint64_t refined_densities;  /* ... and densities the FP64 stage had to evaluate for them (>= 1 per pair) */
+  double prefilter_ms;         /* SR_GMM_PREFILTER: the 16-bit MFMA pass (with the feature transpose) ... */
+  double refine_ms;            /* ... and the FP64 refinement; both are inside gmm_ms */
 } sr_profile;
 SR_API int sr_profile_enable(sr_model* m, int on);
 SR_API int sr_profile_reset(sr_model* m);

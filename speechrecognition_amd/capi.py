@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsrgpu.so")
+# SRGPU_LIB: a differently tuned build of the same library (tools/build_variant.py), for A/B timing only
+LIB_PATH = os.environ.get("SRGPU_LIB") or os.path.join(HERE, "libsrgpu.so")
 
 GMM_MFMA, GMM_EXACT, GMM_PREFILTER = 0, 1, 2
 POOL_GLOBAL, POOL_MIXTURE, POOL_NONE = 0, 1, 2
@@ -39,7 +40,8 @@ class SearchParams(C.Structure):
 class Profile(C.Structure):
     _fields_ = [("gmm_ms", C.c_double), ("gmm_launches", C.c_uint64), ("gmm_flops", C.c_double),
                 ("search_ms", C.c_double), ("search_launches", C.c_uint64), ("search_bytes", C.c_double),
-                ("frames", C.c_uint64), ("refined_pairs", C.c_uint64), ("refined_densities", C.c_uint64)]
+                ("frames", C.c_uint64), ("refined_pairs", C.c_uint64), ("refined_densities", C.c_uint64),
+                ("prefilter_ms", C.c_double), ("refine_ms", C.c_double)]
 
 
 _lib = None

@@ -31,6 +31,10 @@
 
 #include "kernels.h"
 
+#ifndef SR_P16_NB
+#define SR_P16_NB 2   // 16-frame column blocks per wave in the fp16 prefilter
+#endif
+
 namespace srgpu {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -213,8 +217,175 @@ __global__ __launch_bounds__(kPWaves * 64, 3) void gmm_prefilter_kernel(GmmPrefi
   }
 }
 
+// ---- kernel P, fp16 single-product variant ---------------------------------------------------------------------
+// Same structure, a third of the matrix work: both operands rounded ONCE to fp16 (11 significant bits), one MFMA per
+// k-step.  The model side is scaled by a power of two sA (host: largest coefficient or constant -> below 2^14) so
+// that fp16's narrow exponent range is used well; scores, norms and the candidate test stay in scaled units.
+//   |delta a_k| <= 2^-11 |a_k| + 2^-25 / sA (subnormal spacing), |delta b_k| <= 2^-11 |b_k| + 2^-25; products of two
+//   fp16 values are exact in fp32; <= 81 + 3 fp32 additions; konst as an exact 3-term fp16 expansion (33 bits):
+//   |approx - exact| <= (2^-10 (1 + 2^-12) + 87 * 2^-24) |a||b| + 87 * 2^-24 |konst| + 2^-25 (|b|_1 / sA + |a|_1) (1 + 2^-11)
+// -> eps = kKappa16 |a||b| + kKonst16 |konst| + kAbs16 (|b| / sA + |a|),  kKappa16 = 1.05e-3 (needed 9.82e-4),
+//    kKonst16 = 1e-5 (5.2e-6), kAbs16 = 3.1e-8 * sqrt(2 * 46) (|v|_1 <= sqrt(K) |v|_2, needed 2.98e-8 * sqrt(K)).
+// A feature beyond fp16's range (|x| > 255) turns its frame's scores into inf/NaN: every density stays a candidate.
+// About 1.07 candidates per (frame, state) on the bench model instead of 1.01, for a third of the MFMA time.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+static constexpr float kKappa16 = 1.05e-3f, kKonst16 = 1.0e-5f, kAbs16 = 3.0e-7f;
+
+__device__ inline uint32_t pack_f16x2(float lo, float hi) {
+  const _Float16 l = (_Float16)lo, h = (_Float16)hi;
+  return (uint32_t)__builtin_bit_cast(uint16_t, l) | ((uint32_t)__builtin_bit_cast(uint16_t, h) << 16);
+}
+
+// apack16 layout: [block][ks][lane][8 fp16] (rows as in the bf16 kernel); one stage = one group = 8 blocks.
+template <int KS32, int NB>
+__global__ __launch_bounds__(kPWaves * 64, (NB <= 2 ? 3 : 2)) void gmm_prefilter16_kernel(GmmPrefilterArgs a) {
+  constexpr int kBlockBytes = KS32 * 1024;
+  constexpr int kStageBytes = kGroupBlocks * kBlockBytes;
+  constexpr int kChunksPerStage = kStageBytes / 1024;
+  constexpr int kDmaPerWave = kChunksPerStage / kPWaves;
+  static_assert(kChunksPerStage % kPWaves == 0, "every wave issues the same number of LDS-DMA pieces per stage");
+  constexpr int kTileFrames = kPWaves * NB * 16;
+  constexpr size_t kTileBytes = (size_t)kTileFrames * (16 * KS32) * sizeof(float);
+  constexpr size_t kLdsBytes = 2 * kStageBytes > kTileBytes ? 2 * kStageBytes : kTileBytes;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[kLdsBytes];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  uint32_t x, y;
+  {
+    const uint32_t id = blockIdx.x;
+    if ((a.ny & 7u) == 0) { const uint32_t j = id >> 3; y = (id & 7u) + 8u * (j / a.nx); x = j % a.nx; }
+    else { y = id / a.nx; x = id % a.nx; }
+  }
+  const uint32_t g0 = a.split_begin[y], g1 = a.split_begin[y + 1];
+  const uint64_t frame0 = (uint64_t)x * kTileFrames + (uint64_t)wave * (NB * 16);
+
+  // ---- B fragments (fp16) and |b| per frame ---------------------------------------------------------------------
+  uint4 bf[NB][KS32];
+  float bnorm[NB];
+  {
+    float* fl = reinterpret_cast<float*>(lds);
+    const uint64_t tile_first = (uint64_t)x * kTileFrames;
+    const uint64_t tile_frames = (a.n_frames - tile_first < (uint64_t)kTileFrames) ? a.n_frames - tile_first : kTileFrames;
+    const uint32_t n_floats = (uint32_t)tile_frames * a.dim;
+    const float* src = a.feats + tile_first * a.dim;
+    for (uint32_t i = threadIdx.x; i < n_floats; i += kPWaves * 64) fl[i] = src[i];
+    __syncthreads();
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+      const uint32_t row = (uint32_t)wave * (NB * 16) + nb * 16 + c;
+      const bool valid = row < tile_frames;
+      const float* xr = fl + (valid ? row : 0u) * a.dim;
+      float n2 = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < KS32; ks++) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const uint32_t k = 32u * ks + 8u * g + j, d = k >> 1;
+          const float xf = (valid && d < a.dim) ? xr[d < a.dim ? d : 0u] : 0.0f;
+          float b = (k & 1u) ? xf : xf * xf;  // k = 2d -> x^2, 2d+1 -> x   (fp32 rounding of x^2: 2^-24, inside the margin)
+          n2 += b * b;
+          if (valid && k >= 2u * a.dim && k < 2u * a.dim + 3u) b = 1.0f;  // the three konst slots; not part of |b|
+          v[j] = b;
+        }
+        bf[nb][ks] = make_uint4(pack_f16x2(v[0], v[1]), pack_f16x2(v[2], v[3]), pack_f16x2(v[4], v[5]), pack_f16x2(v[6], v[7]));
+      }
+      n2 += __shfl_xor(n2, 16);
+      n2 += __shfl_xor(n2, 32);
+      bnorm[nb] = sqrtf(n2) * 1.0001f;  // rounded up
+    }
+    __syncthreads();
+  }
+
+  auto issue_stage = [&](uint32_t grp, int buf) {
+#pragma unroll
+    for (int i = 0; i < kDmaPerWave; i++) {
+      const int chunk = i * kPWaves + wave;
+      const unsigned char* src = a.apack + (uint64_t)grp * kStageBytes + (uint64_t)chunk * 1024 + lane * 16;
+      unsigned char* dst = lds + buf * kStageBytes + chunk * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+  auto frag = [&](int buf, int j, int ks) -> f16x8 {
+    return __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(lds + buf * kStageBytes + j * kBlockBytes + ks * 1024 + lane * 16));
+  };
+
+  // one stage per group; A fragments are read one k-step ahead, across the stage boundary too (see the bf16 kernel)
+  const uint32_t n_stages = g1 - g0;
+  if (n_stages > 0) issue_stage(g0, 0);
+  if (n_stages > 1) issue_stage(g0 + 1, 1);
+  if (n_stages > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | kDmaPerWave);  // vmcnt(kDmaPerWave): stage 0 has landed
+  else __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  f16x8 a_c, a_n;
+  if (n_stages > 0) a_c = frag(0, 0, 0);
+  for (uint32_t s = 0; s < n_stages; s++) {
+    const uint32_t grp = g0 + s;
+    const int buf = s & 1;
+    v4f ap[NB][kGroupBlocks];
+#pragma unroll
+    for (int j = 0; j < kGroupBlocks; j++) {
+      v4f acc[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) acc[nb] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS32; ks++) {
+        if (j == kGroupBlocks - 1 && ks == KS32 - 1) {
+          if (s + 1 < n_stages) {  // workgroup-uniform
+            __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): stage s+1 landed, my reads of stage s returned
+            __syncthreads();
+            if (s + 2 < n_stages) issue_stage(grp + 2, buf);
+            a_n = frag(buf ^ 1, 0, 0);
+          }
+        } else {
+          a_n = frag(buf, (ks == KS32 - 1) ? j + 1 : j, (ks == KS32 - 1) ? 0 : ks + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nb = 0; nb < NB; nb++)
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_c, __builtin_bit_cast(f16x8, bf[nb][ks]), acc[nb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        a_c = a_n;
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; nb++) ap[nb][j] = acc[nb];
+    }
+    // ---- candidate mask of state slot g of this group, for the lane's frame(s) (scaled units) ---------------------
+    const float2 nk = reinterpret_cast<const float2*>(a.grp_anorm)[4u * grp + g];  // sA |a|, sA |konst| (rounded up)
+#pragma unroll
+    for (int nb = 0; nb < NB; nb++) {
+      float amin = __builtin_huge_valf();
+#pragma unroll
+      for (int j = 0; j < kGroupBlocks; j++) {
+        amin = __builtin_fminf(amin, __builtin_fminf(ap[nb][j][0], ap[nb][j][1]));  // v_min3_f32; fminf drops NaNs
+        amin = __builtin_fminf(amin, __builtin_fminf(ap[nb][j][2], ap[nb][j][3]));
+      }
+      const float limit = amin + 2.0f * (kKappa16 * nk.x * bnorm[nb] + kKonst16 * nk.y + kAbs16 * (bnorm[nb] + nk.x));
+      uint32_t mask = 0;
+#pragma unroll
+      for (int j = kGroupBlocks - 1; j >= 0; j--)
+#pragma unroll
+        for (int i = 3; i >= 0; i--)
+          asm("v_cmp_ngt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(ap[nb][j][i]), "v"(limit) : "vcc");
+      const uint64_t f = frame0 + (uint64_t)nb * 16 + c;
+      if (f < a.n_frames) a.mask[((uint64_t)grp * a.n_frames + f) * 4u + g] = mask;
+    }
+  }
+}
+
 hipError_t launch_gmm_prefilter(const GmmPrefilterArgs& a, int ks32, hipStream_t stream) {
   const dim3 grid(a.nx * a.ny), block(kPWaves * 64);
+  if (a.fp16) {
+    switch (ks32) {
+      case 1: hipLaunchKernelGGL((gmm_prefilter16_kernel<1, SR_P16_NB>), grid, block, 0, stream, a); break;
+      case 2: hipLaunchKernelGGL((gmm_prefilter16_kernel<2, SR_P16_NB>), grid, block, 0, stream, a); break;
+      case 3: hipLaunchKernelGGL((gmm_prefilter16_kernel<3, SR_P16_NB>), grid, block, 0, stream, a); break;
+      default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+  }
   switch (ks32) {
     case 1: hipLaunchKernelGGL((gmm_prefilter_kernel<1, 2>), grid, block, 0, stream, a); break;
     case 2: hipLaunchKernelGGL((gmm_prefilter_kernel<2, 2>), grid, block, 0, stream, a); break;
@@ -223,7 +394,7 @@ hipError_t launch_gmm_prefilter(const GmmPrefilterArgs& a, int ks32, hipStream_t
   }
   return hipGetLastError();
 }
-int gmm_prefilter_frames_per_tile() { return kPWaves * 2 * 16; }
+int gmm_prefilter_frames_per_tile(int fp16) { return kPWaves * (fp16 ? SR_P16_NB : 2) * 16; }
 
 // ---- kernel R ----------------------------------------------------------------------------------------------
 // State-stationary: a workgroup owns SPW (8, or 4 for wide features) consecutive states, whose FP64 parameters fill
@@ -235,9 +406,18 @@ int gmm_prefilter_frames_per_tile() { return kPWaves * 2 * 16; }
 // densities never conflict and lanes on the same density share one broadcast read, whatever the candidates are.
 #pragma clang fp contract(off)
 
-static constexpr int kRThreads = 768;   // 3 waves per SIMD; the register budget of 168 holds x in FP64 (78) + pipeline
+#ifndef SR_R_THREADS
+#define SR_R_THREADS 768
+#endif
+#ifndef SR_R_EXP
+#define SR_R_EXP 0
+#endif
+#ifndef SR_R_BATCH
+#define SR_R_BATCH 4
+#endif
+static constexpr int kRThreads = SR_R_THREADS;   // 3 waves per SIMD; the register budget of 168 holds x in FP64 (78) + pipeline
 static constexpr int kRWaves = kRThreads / 64;
-static constexpr int kRBatch = 4;       // dimensions per software-pipeline stage of the candidate evaluation
+static constexpr int kRBatch = SR_R_BATCH;       // dimensions per software-pipeline stage of the candidate evaluation
 
 template <int DT, int NS, int SPW>  // DT = compile-time feature dimension (0: run-time a.dim, features re-read from featsT)
 __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) {
@@ -271,7 +451,11 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
     double x[DT ? DT : 1];
     if (DT) {
 #pragma unroll
+#if SR_R_EXP == 3  /* timing experiment: no feature loads */
+      for (int k = 0; k < DT; k++) x[k] = (double)(f + k) * 1e-6;
+#else
       for (int k = 0; k < DT; k++) x[k] = (double)a.featsT[(uint64_t)k * a.n_frames_ld + f];
+#endif
     }
     auto X = [&](uint32_t k) -> double { return DT ? x[DT ? k : 0] : (double)a.featsT[(uint64_t)k * a.n_frames_ld + f]; };
     // score of the density whose plane column starts at LDS address `col0`, in density_score_sse's operation order
@@ -296,17 +480,25 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
 #pragma unroll
           for (int i = 0; i < kRBatch; i++) {
             const int k = (b + 1) * kRBatch + i;
+#if SR_R_EXP == 1  /* timing experiment: arithmetic only */
+            if (k <= DT) { pm[cur ^ 1][i] = pm[cur][i] + 1.0; pv[cur ^ 1][i] = pv[cur][i]; }
+#else
             if (k <= DT) { pm[cur ^ 1][i] = col[(2 * k) * NS]; pv[cur ^ 1][i] = col[(2 * k + 1) * NS]; }
+#endif
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int i = 0; i < kRBatch; i++) {
             const int k = b * kRBatch + i;
             if (k < (int)(DT - (DT & 1))) {
+#if SR_R_EXP == 2  /* timing experiment: reads only */
+              if (k & 1) l1 = l1 + pm[cur][i]; else l0 = l0 + pv[cur][i];
+#else
               double u = x[DT ? k : 0] - pm[cur][i];
               u = u * u;
               u = u * pv[cur][i];
               if (k & 1) l1 = l1 + u; else l0 = l0 + u;
+#endif
             } else if (k == DT - 1) {  // odd dimension count: scalar tail (Mixtures.cpp:680-683)
               dist = l0 + l1;
               const double t = x[DT ? k : 0] - pm[cur][i];

@@ -49,6 +49,7 @@ struct GmmPrefilterArgs {
   const uint32_t* split_begin;  // [ny+1] group ranges
   uint32_t* mask;               // [group][frame][4 state slots] candidate densities of (frame, state)
   uint32_t nx, ny;
+  int fp16;                     // 1: single-product fp16 packing ([block][ks][lane][8 fp16]), 0: bf16 hi/lo
 };
 struct GmmRefineArgs {
   const float* featsT;          // [dim x n_frames_ld] transposed features
@@ -64,7 +65,7 @@ struct GmmRefineArgs {
   unsigned long long* n_refined;  // optional: += densities evaluated (profiling)
 };
 hipError_t launch_gmm_prefilter(const GmmPrefilterArgs& a, int ks32, hipStream_t stream);
-int gmm_prefilter_frames_per_tile();
+int gmm_prefilter_frames_per_tile(int fp16);
 int gmm_refine_slots(uint32_t max_dens);
 hipError_t launch_gmm_refine(const GmmRefineArgs& a, hipStream_t stream);
 hipError_t launch_transpose_feats(const float* feats, uint64_t n_frames, uint32_t dim, uint64_t ldT, float* out, hipStream_t stream);

@@ -67,7 +67,7 @@ struct DevBuf {
   void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
 };
 
-struct EventPair { hipEvent_t a, b; int kind; };  // kind 0 = gmm, 1 = search
+struct EventPair { hipEvent_t a, b; int kind; };  // kind 0 = gmm, 1 = search, 2 = prefilter pass, 3 = refinement (inside 0)
 
 }  // namespace
 
@@ -93,6 +93,7 @@ struct sr_model {
   uint32_t split_ny = 0;
   // bf16 prefilter + FP64 refinement (gmm_prefilter.hip); pf_ks32 == 0: model not eligible
   int pf_ks32 = 0;
+  bool pf_fp16 = true;
   uint32_t pf_groups = 0, pf_ny = 0, max_dens = 0, pf_slots = 0;
   DevBuf<unsigned char> pf_apack;
   DevBuf<float> pf_anorm, featsT;
@@ -266,10 +267,40 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
   }
   const int KS = (int)((2 * D + 3 + 31) / 32);
   const uint32_t n_groups = (S + 3) / 4;
-  const size_t blk_bytes = (size_t)KS * 2 * 1024;
-  std::vector<uint16_t> ap((size_t)n_groups * 8 * blk_bytes / 2, 0);
-  std::vector<float> anorm(8 * (size_t)n_groups, 0.0f);  // (|a|, |konst|) per state slot
+  const char* mode = getenv("SRGPU_PF_MODE");  // "bf16": three-product bf16 split (fewer candidates, 3x the MFMA work)
+  const bool fp16 = !(mode && strcmp(mode, "bf16") == 0);
+  m->pf_fp16 = fp16;
+  const float finf = std::numeric_limits<float>::infinity();
+  // per density: coefficients a = [1/(2 var); -mu/var] and the constant
+  auto coeffs = [&](size_t c, std::vector<double>& arow) -> double {
+    double q2 = 0.0;
+    for (uint32_t d = 0; d < D; d++) {
+      const double mu = means[c * D + d], iv = inv_vars[c * D + d];
+      arow[2 * d] = 0.5 * iv;
+      arow[2 * d + 1] = -mu * iv;
+      q2 += mu * mu * iv;
+    }
+    return norm[c] - logw[c] + 0.5 * q2;
+  };
   std::vector<double> arow(32 * (size_t)KS);
+  // fp16: one power-of-two scale for the whole model, the largest finite |coefficient| or |constant| -> [2^13, 2^14)
+  double sA = 1.0;
+  if (fp16) {
+    double big = 0.0;
+    for (size_t c = 0; c < (size_t)m->n_dens; c++) {
+      const double konst = coeffs(c, arow);
+      if (std::isfinite(konst)) big = std::max(big, std::fabs(konst));
+      for (uint32_t k = 0; k < 2 * D; k++)
+        if (std::isfinite(arow[k])) big = std::max(big, std::fabs(arow[k]));
+    }
+    if (big > 0.0) sA = std::ldexp(1.0, 13 - std::ilogb(big));
+  }
+  const size_t parts = fp16 ? 1 : 2;
+  const size_t blk_bytes = (size_t)KS * parts * 1024;
+  std::vector<uint16_t> ap((size_t)n_groups * 8 * blk_bytes / 2, 0);
+  std::vector<float> anorm(8 * (size_t)n_groups, 0.0f);  // (sA |a|, sA |konst|) per state slot
+  auto half_bits = [](double v) { const _Float16 h = (_Float16)(float)v; uint16_t u; memcpy(&u, &h, 2); return u; };
+  auto half_value = [](uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (double)(float)h; };
   for (uint32_t q = 0; q < n_groups; q++) {
     for (uint32_t j = 0; j < 8; j++) {
       const size_t b = (size_t)q * 8 + j;
@@ -277,42 +308,38 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
         const uint32_t g = r >> 2, st = 4 * q + g, i = 4 * j + (r & 3);
         const bool real = st < S && i < dens_off[st + 1] - dens_off[st];
         std::fill(arow.begin(), arow.end(), 0.0);
-        const float finf = std::numeric_limits<float>::infinity();
-        double konst = 3.0e38;  // padding slot: never below a real score, masked off again by the refinement
+        double konst = fp16 ? (double)finf : 3.0e38;  // padding slot: never below a real score, masked off again by the refinement
         if (real) {
-          const size_t c = (size_t)dens_off[st] + i;
-          double q2 = 0.0, n2 = 0.0;
-          for (uint32_t d = 0; d < D; d++) {
-            const double mu = means[c * D + d], iv = inv_vars[c * D + d];
-            arow[2 * d] = 0.5 * iv;
-            arow[2 * d + 1] = -mu * iv;
-            q2 += mu * mu * iv;
-          }
-          konst = norm[c] - logw[c] + 0.5 * q2;
-          for (uint32_t k = 0; k < 2 * D; k++) n2 += arow[k] * arow[k];
+          konst = coeffs((size_t)dens_off[st] + i, arow) * sA;
+          double n2 = 0.0;
+          for (uint32_t k = 0; k < 2 * D; k++) { arow[k] *= sA; n2 += arow[k] * arow[k]; }
           const float na = std::nextafter((float)(std::sqrt(n2) * (1.0 + 1e-6)), finf);
           const float nk = std::nextafter((float)(std::fabs(konst) * (1.0 + 1e-6)), finf);
           // NaN sticks: everything of that state then stays a candidate
           if (!(na <= anorm[2 * (4 * q + g)])) anorm[2 * (4 * q + g)] = na;
           if (!(nk <= anorm[2 * (4 * q + g) + 1])) anorm[2 * (4 * q + g) + 1] = nk;
         }
-        // konst = c1 + c2 + c3 in bf16 (24 bits), multiplied by 1 in three spare k slots: exact products
+        // konst = c1 + c2 + c3 (3 x 8 bits in bf16, 3 x 11 in fp16), multiplied by 1 in three spare k slots: exact products
         double rest = konst;
         for (uint32_t t = 0; t < 3; t++) {
-          const float c = bf16_to_float(bf16_rne((float)rest));
+          const double c = (real || t == 0) ? (fp16 ? half_value(half_bits(rest)) : (double)bf16_to_float(bf16_rne((float)rest))) : 0.0;
           arow[2 * D + t] = c;
-          rest -= (double)c;
+          rest -= c;
         }
         for (int ks = 0; ks < KS; ks++)
           for (uint32_t kk = 0; kk < 32; kk++) {
             const uint32_t k = 32 * ks + kk;
             const double v = arow[k];
-            const uint16_t hi = bf16_rne((float)v);
-            const uint16_t lo = (real && k < 2 * D) ? bf16_rne((float)(v - (double)bf16_to_float(hi))) : (uint16_t)0;
             const uint32_t lane = r + 16 * (kk >> 3), e = kk & 7;
-            const size_t base = (b * blk_bytes) / 2 + (size_t)ks * 1024 + (size_t)lane * 8 + e;
-            ap[base] = hi;
-            ap[base + 512] = lo;
+            if (fp16) {
+              ap[(b * blk_bytes) / 2 + (size_t)ks * 512 + (size_t)lane * 8 + e] = half_bits(v);
+            } else {
+              const uint16_t hi = bf16_rne((float)v);
+              const uint16_t lo = (real && k < 2 * D) ? bf16_rne((float)(v - (double)bf16_to_float(hi))) : (uint16_t)0;
+              const size_t base = (b * blk_bytes) / 2 + (size_t)ks * 1024 + (size_t)lane * 8 + e;
+              ap[base] = hi;
+              ap[base + 512] = lo;
+            }
           }
       }
     }
@@ -397,7 +424,7 @@ int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm
     HIP_TRY(launch_gmm_mfma(a, m->ksteps, !m->max_approx, m->s_gmm));
     if ((rc = prof_end(m, m->s_gmm, &ep))) return rc;
   } else if (gmm_kernel == SR_GMM_PREFILTER && m->pf_ks32 > 0) {
-    const uint32_t tile = gmm_prefilter_frames_per_tile();
+    const uint32_t tile = gmm_prefilter_frames_per_tile(m->pf_fp16);
     const uint32_t nx = (uint32_t)((n_frames + tile - 1) / tile);
     int rc = set_prefilter_splits(m, nx);
     if (rc) return rc;
@@ -407,17 +434,22 @@ int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm
     GmmPrefilterArgs pa{};
     pa.feats = d_feats; pa.n_frames = n_frames; pa.dim = m->dim;
     pa.apack = m->pf_apack.p; pa.grp_anorm = m->pf_anorm.p; pa.split_begin = m->pf_split.p;
-    pa.mask = m->pf_mask.p; pa.nx = nx; pa.ny = m->pf_ny;
+    pa.mask = m->pf_mask.p; pa.nx = nx; pa.ny = m->pf_ny; pa.fp16 = m->pf_fp16;
     GmmRefineArgs ra{};
     ra.featsT = m->featsT.p; ra.n_frames = n_frames; ra.n_frames_ld = ldT; ra.dim = m->dim; ra.n_states = m->n_states;
     ra.max_dens = m->max_dens; ra.dens_off = m->dens_off.p; ra.rows = m->pf_rows.p; ra.n_slots = m->pf_slots;
     ra.mask = m->pf_mask.p; ra.out = d_out; ra.ld = m->ld;
     ra.n_refined = m->profiling ? m->pf_counter.p : nullptr;
     if (m->profiling) m->prof.refined_pairs += n_frames * (uint64_t)m->n_states;
+    EventPair ep_p{}, ep_r{};
     if ((rc = prof_begin(m, m->s_gmm, 0, &ep))) return rc;
+    if ((rc = prof_begin(m, m->s_gmm, 2, &ep_p))) return rc;
     HIP_TRY(launch_transpose_feats(d_feats, n_frames, m->dim, ldT, m->featsT.p, m->s_gmm));
     HIP_TRY(launch_gmm_prefilter(pa, m->pf_ks32, m->s_gmm));
+    if ((rc = prof_end(m, m->s_gmm, &ep_p))) return rc;
+    if ((rc = prof_begin(m, m->s_gmm, 3, &ep_r))) return rc;
     HIP_TRY(launch_gmm_refine(ra, m->s_gmm));
+    if ((rc = prof_end(m, m->s_gmm, &ep_r))) return rc;
     if ((rc = prof_end(m, m->s_gmm, &ep))) return rc;
   } else if (gmm_kernel == SR_GMM_EXACT || gmm_kernel == SR_GMM_PREFILTER) {
     // (a model the prefilter cannot take -- sum scoring, > 32 densities per mixture, dim > 47 -- is scored by the
@@ -1038,7 +1070,9 @@ int sr_profile_read(sr_model* m, sr_profile* out) {
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, ep.a, ep.b));
     if (ep.kind == 0) { m->prof.gmm_ms += ms; m->prof.gmm_launches++; }
-    else { m->prof.search_ms += ms; m->prof.search_launches++; }
+    else if (ep.kind == 1) { m->prof.search_ms += ms; m->prof.search_launches++; }
+    else if (ep.kind == 2) m->prof.prefilter_ms += ms;
+    else m->prof.refine_ms += ms;
     (void)hipEventDestroy(ep.a);
     (void)hipEventDestroy(ep.b);
   }

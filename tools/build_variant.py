@@ -1,0 +1,27 @@
+"""Builds libsrgpu variants with different compile-time tuning constants for A/B timing on the GPU box.
+
+usage: python tools/build_variant.py NAME -DSR_R_THREADS=512 -DSR_R_BATCH=8 ...
+  -> speechrecognition_amd/csrc/build/variants/libsrgpu_NAME.so   (select with SRGPU_LIB=<path>)
+"""
+import os, subprocess, sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+from speechrecognition_amd import build as B
+
+name, defs = sys.argv[1], sys.argv[2:]
+out_dir = os.path.join(B.CSRC, "build", "variants", name)
+os.makedirs(out_dir, exist_ok=True)
+objs = []
+procs = []
+for src in B.SOURCES:
+    obj = os.path.join(out_dir, src + ".o")
+    objs.append(obj)
+    cmd = ["hipcc", "-x", "hip", "-c", os.path.join(B.CSRC, src), "-o", obj] + B.FLAGS + B.PER_FILE.get(src, []) + defs
+    procs.append(subprocess.Popen(cmd))
+for p in procs:
+    if p.wait() != 0:
+        sys.exit(1)
+lib = os.path.join(B.CSRC, "build", "variants", f"libsrgpu_{name}.so")
+subprocess.check_call(["hipcc", "-shared", "-o", lib] + objs + ["--offload-arch=gfx950"])
+print(lib)
