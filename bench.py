@@ -219,16 +219,19 @@ def prefilter_report(args, prof, n_frames, D, S):
 
 
 def pmc_traffic(args, n_frames, kernel="gmm_mfma_kernel"):
-    """HBM bytes per GMM launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside the
-    timed process); only reported when they were taken on this very workload, else null."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_summary.json")
+    """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (tools/profile_bench.sh;
+    rocprofv3 cannot run inside the timed process); only reported when they were taken on this very workload."""
+    path = os.path.join(ROOT, "profiles", "r1_prefilter_summary.json" if args.kernel == "prefilter" else "r1_mfma_summary.json")
     try:
         z = json.load(open(path))
     except (OSError, ValueError):
         return None
-    if z.get("workload_frames_per_launch") != n_frames or args.words != 1333 or args.mix != 32 or kernel not in z:
+    if z.get("workload_frames_per_launch") != n_frames or args.words != 1333 or args.mix != 32:
         return None
-    return z[kernel]["hbm_bytes_per_launch_corrected"]
+    for name, k in z.get("kernels", {}).items():
+        if name.startswith(kernel):
+            return k.get("hbm_bytes_per_launch_corrected")
+    return None
 
 
 def usable_cores():

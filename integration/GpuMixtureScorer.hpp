@@ -41,7 +41,7 @@ public:
     const size_t n_frames = end - start;
     start_ = *start;
     table_.resize(n_frames * num_states_);
-    if (sr_score_frames(model_, *start, n_frames, SR_GMM_MFMA, table_.data()) != SR_OK) {
+    if (sr_score_frames(model_, *start, n_frames, SR_GMM_PREFILTER, table_.data()) != SR_OK) {
       throw std::runtime_error(sr_last_error());
     }
   }
@@ -88,7 +88,7 @@ inline void gpu_recognize(GpuMixtureScorer const& scorer, Lexicon const& lexicon
   }
   std::vector<uint32_t> words(frame_off[corpus_size] + 1);
   std::vector<uint64_t> out_off(corpus_size + 1);
-  sr_search_params p = {am_threshold, word_penalty, SR_GMM_MFMA, 0};
+  sr_search_params p = {am_threshold, word_penalty, SR_GMM_PREFILTER, 0};
   const int rc = sr_recognize_batch(scorer.handle(), net, &p, *corpus.get_feature_sequence(0).first, frame_off.data(),
                                     corpus_size, words.data(), out_off.data());
   sr_lexicon_destroy(net);

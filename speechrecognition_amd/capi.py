@@ -149,7 +149,7 @@ class Model:
         self.close()
 
     # -- scoring -----------------------------------------------------------------------------------
-    def score_frames(self, feats, kernel=GMM_MFMA):
+    def score_frames(self, feats, kernel=GMM_PREFILTER):
         feats = np.ascontiguousarray(feats, dtype=np.float32)
         out = np.empty((feats.shape[0], self.n_states), dtype=np.float64)
         _check(lib().sr_score_frames(self.h, _ptr(feats), feats.shape[0], kernel, _ptr(out)))
@@ -189,12 +189,12 @@ class Corpus:
             lib().sr_corpus_destroy(self.h)
             self.h = None
 
-    def score(self, kernel=GMM_MFMA):
+    def score(self, kernel=GMM_PREFILTER):
         out = np.empty((self.n_frames, self.model.n_states), dtype=np.float64)
         _check(lib().sr_score_corpus(self.model.h, self.h, kernel, _ptr(out)))
         return out
 
-    def recognize(self, lexicon, am_threshold, word_penalty, kernel=GMM_MFMA, traceback=False):
+    def recognize(self, lexicon, am_threshold, word_penalty, kernel=GMM_PREFILTER, traceback=False):
         """-> (words u32[], word_off u64[n_utts+1]) [, (tb_score, tb_word, tb_bkp)]"""
         words = np.zeros(max(self.n_frames, 1), dtype=np.uint32)
         woff = np.zeros(self.n_utts + 1, dtype=np.uint64)
@@ -215,7 +215,7 @@ class Corpus:
         off = np.concatenate([[0], np.cumsum([len(a) for a in automata])]).astype(np.uint64)
         return flat, off
 
-    def align(self, automata, tdp, silence_state, kernel=GMM_MFMA, pruning_threshold=None):
+    def align(self, automata, tdp, silence_state, kernel=GMM_PREFILTER, pruning_threshold=None):
         """automata: one state-id sequence per utterance -> (states u16[total_frames], cost f64[n_utts])"""
         flat, off = self._aut(automata)
         states = np.zeros(max(self.n_frames, 1), dtype=np.uint16)
@@ -241,7 +241,7 @@ class Corpus:
                                           _ptr(va), _ptr(vw)))
         return ma, mw, va, vw
 
-    def path_scores(self, states, kernel=GMM_MFMA):
+    def path_scores(self, states, kernel=GMM_PREFILTER):
         """Emission cost along a state path (one state per frame): Trainer::calc_am_score's summands."""
         states = np.ascontiguousarray(states, dtype=np.uint16)
         out = np.zeros(max(self.n_frames, 1), dtype=np.float64)

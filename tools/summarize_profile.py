@@ -1,0 +1,50 @@
+"""Condenses a tools/profile_bench.sh run into one JSON: per-kernel average durations (rocprofv3 --stats) and PMC
+counters per dispatch, with the gfx950 corrections of MI355X_MICROARCH.md (HBM section): FETCH_SIZE doubled (wide
+coalesced reads are tallied at half their bytes), WRITE_SIZE as is, both in KB.
+
+usage: python3 tools/summarize_profile.py gpurun_out/profile_TAG  -> gpurun_out/profile_TAG/summary.json (+ stdout)
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+root = sys.argv[1]
+short = lambda n: n.split("(")[0].replace("void ", "").replace("srgpu::", "")
+out = {"source": "tools/profile_bench.sh: rocprofv3 --kernel-trace --stats (3 timed steps + 1 warm-up) and one "
+                 "rocprofv3 --pmc pass per counter group (1 step + 1 warm-up) of python3 bench.py, MI355X",
+       "kernels": {}}
+try:
+    out["bench_line_under_profiler"] = json.loads(open(os.path.join(root, "bench_under_profiler.json")).read())
+    out["workload_frames_per_launch"] = out["bench_line_under_profiler"]["config"]["frames_per_gpu_rank0"]
+except (OSError, ValueError, KeyError):
+    pass
+for r in csv.DictReader(open(os.path.join(root, "stats", "s_kernel_stats.csv"))):
+    if float(r["AverageNs"]) >= 2e4:
+        out["kernels"][short(r["Name"])] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
+                                             "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6,
+                                             "share_pct": float(r["Percentage"])}
+for path in sorted(glob.glob(os.path.join(root, "pmc*", "p_counter_collection.csv"))):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    per_dispatch = collections.defaultdict(float)
+    for r in csv.DictReader(open(path)):
+        per_dispatch[(short(r["Kernel_Name"]), r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
+    for (k, _, c), v in per_dispatch.items():
+        agg[k][c].append(v)
+    for k, cs in agg.items():
+        if k in out["kernels"]:
+            for c, vals in cs.items():
+                out["kernels"][k].setdefault("pmc_mean_per_dispatch", {})[c] = sum(vals) / len(vals)
+for k, z in out["kernels"].items():
+    p = z.get("pmc_mean_per_dispatch", {})
+    if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
+        z["hbm_bytes_per_launch_corrected"] = (2.0 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024.0
+        z["correction"] = "gfx950: FETCH_SIZE x2 (wide coalesced reads tallied at half their bytes), WRITE_SIZE exact; unit KB"
+    if "GRBM_GUI_ACTIVE" in p:
+        z["clock_GHz_from_GRBM_GUI_ACTIVE"] = p["GRBM_GUI_ACTIVE"] / 8.0 / (z["avg_ms"] * 1e-3) / 1e9
+    if "TCC_HIT_sum" in p:
+        z["l2_hit_rate"] = p["TCC_HIT_sum"] / max(1.0, p["TCC_HIT_sum"] + p["TCC_MISS_sum"])
+json.dump(out, open(os.path.join(root, "summary.json"), "w"), indent=1)
+print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "pmc_mean_per_dispatch"} for k, v in out["kernels"].items()}, indent=1))
