@@ -43,9 +43,9 @@ extern "C" {
 /* GMM scoring kernels (MixtureModel::score, Mixtures.cpp:737-744) */
 #define SR_GMM_MFMA 0   /* FP64 MFMA contraction + fused min / log-sum epilogue (default; ~1e-15 rel.) */
 #define SR_GMM_EXACT 1  /* direct form replaying density_score_sse's operation order (Mixtures.cpp:645-690): bit-exact */
-#define SR_GMM_PREFILTER 2  /* bit-exact like SR_GMM_EXACT: a bf16 MFMA prefilter selects the densities that can be the
-                               minimum, FP64 replays only those.  Max-approx models with <= 32 densities per mixture and
-                               dim <= 47; any other model is scored by SR_GMM_EXACT's kernel instead (same bits). */
+#define SR_GMM_PREFILTER 2  /* bit-exact like SR_GMM_EXACT: a 16-bit MFMA prefilter selects the densities that can be the
+                               minimum, FP64 replays only those.  Max-approx models with <= 128 densities per mixture and
+                               dim <= 46; any other model is scored by SR_GMM_EXACT's kernel instead (same bits). */
 
 typedef struct sr_model sr_model;     /* replaces MixtureModel as a FeatureScorer (Mixtures.hpp:18, FeatureScorer.hpp:12-16) */
 typedef struct sr_corpus sr_corpus;   /* replaces Corpus' feature store (Corpus.hpp:79-84, Corpus.cpp:141-144) */

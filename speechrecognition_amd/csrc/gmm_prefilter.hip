@@ -22,8 +22,9 @@
 // MixtureModel::score returns.  P is MFMA/LDS-DMA bound (bf16), R is FP64-VALU/LDS bound with about one density
 // per (frame, state) instead of thirty-two.
 //
-// Limits of this path: max-approx only, <= 32 densities per mixture, dim <= 46 (K = 2*dim + 3 <= 96); any other
-// model is scored by the exact FP64 kernel (same bits).
+// Limits of this path: max-approx only, <= 128 densities per mixture (a mixture of more than 32 spans 2 or 4
+// consecutive 32-slot pseudo-states), dim <= 46 (K = 2*dim + 3 <= 96); any other model is scored by the exact FP64
+// kernel (same bits).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -202,6 +203,8 @@ __global__ __launch_bounds__(kPWaves * 64, 3) void gmm_prefilter_kernel(GmmPrefi
         amin = __builtin_fminf(amin, __builtin_fminf(ap[nb][j][0], ap[nb][j][1]));  // v_min3_f32; fminf drops NaNs
         amin = __builtin_fminf(amin, __builtin_fminf(ap[nb][j][2], ap[nb][j][3]));
       }
+      if (a.chunks >= 2) amin = __builtin_fminf(amin, __shfl_xor(amin, 16));  // the other chunk(s) of the same state
+      if (a.chunks >= 4) amin = __builtin_fminf(amin, __shfl_xor(amin, 32));
       const float limit = amin + 2.0f * ((kKappa * 1.001f) * nk.x * bnorm[nb] + kKonst * nk.y);
       // mask = 2*mask + !(value > limit), densities in descending order: one compare + one add-with-carry per density.
       // NaN (bad variance) or an infinite limit: stay candidates.
@@ -362,6 +365,8 @@ __global__ __launch_bounds__(kPWaves * 64, (NB <= 2 ? 3 : 2)) void gmm_prefilter
         amin = __builtin_fminf(amin, __builtin_fminf(ap[nb][j][0], ap[nb][j][1]));  // v_min3_f32; fminf drops NaNs
         amin = __builtin_fminf(amin, __builtin_fminf(ap[nb][j][2], ap[nb][j][3]));
       }
+      if (a.chunks >= 2) amin = __builtin_fminf(amin, __shfl_xor(amin, 16));  // the other chunk(s) of the same state
+      if (a.chunks >= 4) amin = __builtin_fminf(amin, __shfl_xor(amin, 32));
       const float limit = amin + 2.0f * (kKappa16 * nk.x * bnorm[nb] + kKonst16 * nk.y + kAbs16 * (bnorm[nb] + nk.x));
       uint32_t mask = 0;
 #pragma unroll
@@ -425,7 +430,7 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
   const uint32_t D = DT ? (uint32_t)DT : a.dim, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const uint32_t s0 = blockIdx.x * SPW;
-  const uint32_t ns = (s0 + SPW <= a.n_states) ? SPW : a.n_states - s0;  // states of this workgroup
+  const uint32_t ns = (s0 + SPW <= a.n_pstates) ? SPW : a.n_pstates - s0;  // (pseudo-)states of this workgroup
   const uint32_t state_bytes = (2u * D + 2u) * NS * 8u;
   const uint32_t D2 = D - (D & 1u);
   const uint64_t f_begin = (uint64_t)blockIdx.y * a.frames_per_split;
@@ -442,7 +447,7 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
   }
   uint32_t nd[SPW];  // densities per state (wave-uniform)
 #pragma unroll
-  for (int j = 0; j < SPW; j++) nd[j] = (uint32_t)j < ns ? a.dens_off[s0 + j + 1] - a.dens_off[s0 + j] : 0u;
+  for (int j = 0; j < SPW; j++) nd[j] = (uint32_t)j < ns ? a.n_dens_ps[s0 + j] : 0u;
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __syncthreads();
 
@@ -579,14 +584,34 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
       for (int j = 0; j < SPW; j++)
         if (j == jsel && score < res[j]) res[j] = score;
     }
-    double* o = a.out + f * a.ld + s0;
-    if (ns == SPW) {  // ld is a multiple of 8: 64-byte (32-byte for SPW = 4) aligned pieces
+    // a mixture of more than 32 densities spans `chunks` consecutive pseudo-states: fold their minima (NaN never
+    // wins, as in the reference's scan)
+    if (a.chunks == 1) {
+      double* o = a.out + f * a.ld + s0;
+      if (ns == SPW) {  // ld is a multiple of 8: 64-byte (32-byte for SPW = 4) aligned pieces
 #pragma unroll
-      for (int j = 0; j < SPW; j += 2) *reinterpret_cast<double2*>(o + j) = make_double2(res[j], res[j + 1]);
-    } else {
+        for (int j = 0; j < SPW; j += 2) *reinterpret_cast<double2*>(o + j) = make_double2(res[j], res[j + 1]);
+      } else {
 #pragma unroll
-      for (int j = 0; j < SPW; j++)
-        if ((uint32_t)j < ns) o[j] = res[j];
+        for (int j = 0; j < SPW; j++)
+          if ((uint32_t)j < ns) o[j] = res[j];
+      }
+    } else if (a.chunks == 2) {
+      double* o = a.out + f * a.ld + s0 / 2;
+#pragma unroll
+      for (int j = 0; j < SPW; j += 2) {
+        const double m = res[j + 1] < res[j] ? res[j + 1] : res[j];
+        if ((uint32_t)j < ns) o[j / 2] = m;
+      }
+    } else {  // 4
+      double* o = a.out + f * a.ld + s0 / 4;
+#pragma unroll
+      for (int j = 0; j < SPW; j += 4) {
+        double m = res[j + 1] < res[j] ? res[j + 1] : res[j];
+        m = res[j + 2] < m ? res[j + 2] : m;
+        m = res[j + 3] < m ? res[j + 3] : m;
+        if ((uint32_t)j < ns) o[j / 4] = m;
+      }
     }
   }
   if (a.n_refined) {
@@ -626,7 +651,7 @@ static hipError_t launch_refine_ns(const GmmRefineArgs& a0, hipStream_t stream) 
   GmmRefineArgs a = a0;
   const size_t state_bytes = (size_t)(2 * a.dim + 2) * NS * 8;
   const size_t smem = (SPW * state_bytes + 1023) & ~(size_t)1023;
-  const uint32_t n_sgroups = (a.n_states + SPW - 1) / SPW;
+  const uint32_t n_sgroups = (a.n_pstates + SPW - 1) / SPW;
   // two rounds of workgroups over the 256 CUs at least (one workgroup per CU when it takes the whole LDS), without
   // cutting the frame range below one pass of the threads
   uint64_t splits = std::max<uint64_t>(1, (512 + n_sgroups - 1) / n_sgroups);

@@ -49,13 +49,14 @@ struct GmmPrefilterArgs {
   const uint32_t* split_begin;  // [ny+1] group ranges
   uint32_t* mask;               // [group][frame][4 state slots] candidate densities of (frame, state)
   uint32_t nx, ny;
+  uint32_t chunks;              // 1, 2 or 4 consecutive state slots (of 32 densities) make up one state
   int fp16;                     // 1: single-product fp16 packing ([block][ks][lane][8 fp16]), 0: bf16 hi/lo
 };
 struct GmmRefineArgs {
   const float* featsT;          // [dim x n_frames_ld] transposed features
   uint64_t n_frames, n_frames_ld;
-  uint32_t dim, n_states, max_dens;
-  const uint32_t* dens_off;
+  uint32_t dim, n_pstates, chunks;  // pseudo-states = states x chunks (a state of up to 32*chunks densities)
+  const uint32_t* n_dens_ps;    // [n_pstates] densities in each pseudo-state (0..32)
   const double* rows;           // [state][2*dim + 2 planes][n_slots]: mu_0, 1/var_0, ..., norm, logw per density slot;
                                 // 1 KB of slack after the last state
   uint32_t n_slots;             // gmm_refine_slots(max_dens): 8, 16 or 32

@@ -94,10 +94,10 @@ struct sr_model {
   // bf16 prefilter + FP64 refinement (gmm_prefilter.hip); pf_ks32 == 0: model not eligible
   int pf_ks32 = 0;
   bool pf_fp16 = true;
-  uint32_t pf_groups = 0, pf_ny = 0, max_dens = 0, pf_slots = 0;
+  uint32_t pf_groups = 0, pf_ny = 0, max_dens = 0, pf_slots = 0, pf_chunks = 1, pf_pstates = 0;
   DevBuf<unsigned char> pf_apack;
   DevBuf<float> pf_anorm, featsT;
-  DevBuf<uint32_t> pf_split, pf_mask;
+  DevBuf<uint32_t> pf_split, pf_mask, pf_ndens;
   DevBuf<double> pf_rows;
   DevBuf<unsigned long long> pf_counter;
   // streams / workspace
@@ -247,17 +247,32 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
   for (uint32_t s = 0; s < S; s++) mx = std::max(mx, dens_off[s + 1] - dens_off[s]);
   m->max_dens = std::max(1u, mx);
   m->pf_ks32 = 0;
-  if (!m->max_approx || mx > 32 || 2 * D + 3 > 96) return SR_OK;  // not eligible: callers get the exact kernel
-  // FP64 planes for the refinement: [state][mu_0 | 1/var_0 | ... | norm | logw][density slot]; 1 KB of slack for the
-  // LDS-DMA's last piece
+  if (!m->max_approx || mx > 128 || 2 * D + 3 > 96) return SR_OK;  // not eligible: callers get the exact kernel
+  // A mixture of more than 32 densities is cut into Cs = 2 or 4 chunks of 32: the kernels see S*Cs pseudo-states
+  // (ps = st*Cs + chunk), the prefilter takes the minimum across a state's chunks, the refinement folds them.
+  const uint32_t Cs = mx <= 32 ? 1u : mx <= 64 ? 2u : 4u;
+  const uint32_t PS = S * Cs;
+  m->pf_chunks = Cs;
+  m->pf_pstates = PS;
+  auto ps_count = [&](uint32_t ps) -> uint32_t {  // densities of pseudo-state ps
+    const uint32_t n = dens_off[ps / Cs + 1] - dens_off[ps / Cs], lo = 32u * (ps % Cs);
+    return n > lo ? std::min(32u, n - lo) : 0u;
+  };
   {
-    const uint32_t NS = (uint32_t)gmm_refine_slots(m->max_dens), planes = 2 * D + 2;
+    std::vector<uint32_t> cnt(PS);
+    for (uint32_t ps = 0; ps < PS; ps++) cnt[ps] = ps_count(ps);
+    HIP_TRY(m->pf_ndens.upload(cnt.data(), cnt.size()));
+  }
+  // FP64 planes for the refinement: [pseudo-state][mu_0 | 1/var_0 | ... | norm | logw][density slot]; 1 KB of slack
+  // for the LDS-DMA's last piece
+  {
+    const uint32_t NS = (uint32_t)gmm_refine_slots(std::min(32u, m->max_dens)), planes = 2 * D + 2;
     m->pf_slots = NS;
-    std::vector<double> rows((size_t)S * planes * NS + 128, 0.0);
-    for (uint32_t st = 0; st < S; st++) {
-      double* r = rows.data() + (size_t)st * planes * NS;
-      for (uint32_t i = 0; i < dens_off[st + 1] - dens_off[st]; i++) {
-        const size_t c = (size_t)dens_off[st] + i;
+    std::vector<double> rows((size_t)PS * planes * NS + 128, 0.0);
+    for (uint32_t ps = 0; ps < PS; ps++) {
+      double* r = rows.data() + (size_t)ps * planes * NS;
+      for (uint32_t i = 0; i < ps_count(ps); i++) {
+        const size_t c = (size_t)dens_off[ps / Cs] + 32u * (ps % Cs) + i;
         for (uint32_t d = 0; d < D; d++) { r[(2 * d) * NS + i] = means[c * D + d]; r[(2 * d + 1) * NS + i] = inv_vars[c * D + d]; }
         r[(2 * D) * NS + i] = norm[c];
         r[(2 * D + 1) * NS + i] = logw[c];
@@ -266,7 +281,7 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
     HIP_TRY(m->pf_rows.upload(rows.data(), rows.size()));
   }
   const int KS = (int)((2 * D + 3 + 31) / 32);
-  const uint32_t n_groups = (S + 3) / 4;
+  const uint32_t n_groups = (PS + 3) / 4;
   const char* mode = getenv("SRGPU_PF_MODE");  // "bf16": three-product bf16 split (fewer candidates, 3x the MFMA work)
   const bool fp16 = !(mode && strcmp(mode, "bf16") == 0);
   m->pf_fp16 = fp16;
@@ -305,12 +320,13 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
     for (uint32_t j = 0; j < 8; j++) {
       const size_t b = (size_t)q * 8 + j;
       for (uint32_t r = 0; r < 16; r++) {
-        const uint32_t g = r >> 2, st = 4 * q + g, i = 4 * j + (r & 3);
-        const bool real = st < S && i < dens_off[st + 1] - dens_off[st];
+        const uint32_t g = r >> 2, ps = 4 * q + g, i = 4 * j + (r & 3);
+        const bool real = ps < PS && i < ps_count(ps);
+        const uint32_t st = ps < PS ? ps / Cs : 0;
         std::fill(arow.begin(), arow.end(), 0.0);
         double konst = fp16 ? (double)finf : 3.0e38;  // padding slot: never below a real score, masked off again by the refinement
         if (real) {
-          konst = coeffs((size_t)dens_off[st] + i, arow) * sA;
+          konst = coeffs((size_t)dens_off[st] + 32u * (ps % Cs) + i, arow) * sA;
           double n2 = 0.0;
           for (uint32_t k = 0; k < 2 * D; k++) { arow[k] *= sA; n2 += arow[k] * arow[k]; }
           const float na = std::nextafter((float)(std::sqrt(n2) * (1.0 + 1e-6)), finf);
@@ -343,6 +359,17 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
           }
       }
     }
+  }
+  if (Cs > 1) {  // the candidate test of every chunk uses the whole state's largest |a| and |konst|
+    for (uint32_t st = 0; st < S; st++)
+      for (int f = 0; f < 2; f++) {
+        float mxv = 0.0f;
+        for (uint32_t ch = 0; ch < Cs; ch++) {
+          const float v = anorm[2 * (size_t)(st * Cs + ch) + f];
+          if (!(v <= mxv)) mxv = v;
+        }
+        for (uint32_t ch = 0; ch < Cs; ch++) anorm[2 * (size_t)(st * Cs + ch) + f] = mxv;
+      }
   }
   HIP_TRY(m->pf_apack.upload(reinterpret_cast<const unsigned char*>(ap.data()), ap.size() * 2));
   HIP_TRY(m->pf_anorm.upload(anorm.data(), anorm.size()));
@@ -434,10 +461,10 @@ int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm
     GmmPrefilterArgs pa{};
     pa.feats = d_feats; pa.n_frames = n_frames; pa.dim = m->dim;
     pa.apack = m->pf_apack.p; pa.grp_anorm = m->pf_anorm.p; pa.split_begin = m->pf_split.p;
-    pa.mask = m->pf_mask.p; pa.nx = nx; pa.ny = m->pf_ny; pa.fp16 = m->pf_fp16;
+    pa.mask = m->pf_mask.p; pa.nx = nx; pa.ny = m->pf_ny; pa.fp16 = m->pf_fp16; pa.chunks = m->pf_chunks;
     GmmRefineArgs ra{};
-    ra.featsT = m->featsT.p; ra.n_frames = n_frames; ra.n_frames_ld = ldT; ra.dim = m->dim; ra.n_states = m->n_states;
-    ra.max_dens = m->max_dens; ra.dens_off = m->dens_off.p; ra.rows = m->pf_rows.p; ra.n_slots = m->pf_slots;
+    ra.featsT = m->featsT.p; ra.n_frames = n_frames; ra.n_frames_ld = ldT; ra.dim = m->dim; ra.n_pstates = m->pf_pstates; ra.chunks = m->pf_chunks;
+    ra.n_dens_ps = m->pf_ndens.p; ra.rows = m->pf_rows.p; ra.n_slots = m->pf_slots;
     ra.mask = m->pf_mask.p; ra.out = d_out; ra.ld = m->ld;
     ra.n_refined = m->profiling ? m->pf_counter.p : nullptr;
     if (m->profiling) m->prof.refined_pairs += n_frames * (uint64_t)m->n_states;

@@ -447,7 +447,10 @@ def test_em_iteration_matches_reference_model_file(tmp_path, oracle_lib):
     (904, 24, 16, 39, 1.0, 1e-4, False),    # tiny variances: coefficients ~ 1e4, GEMM-form cancellation
     (905, 24, 8, 46, 1.0, 0.5, True),       # dim 46 (K = 95, the limit) and duplicated densities (exact ties)
     (906, 24, 8, 12, 1.0, 0.5, False),      # dim 12 -> one 32-wide k-step
-    (907, 16, 40, 39, 1.0, 0.5, False),     # 40 densities per mixture: not eligible -> exact kernel, same bits
+    (907, 16, 40, 39, 1.0, 0.5, False),     # 40 densities per mixture: two 32-slot chunks per state
+    (909, 13, 64, 39, 1.0, 0.5, False),     # 64 (BASELINE configs[4] mixtures), odd state count
+    (910, 11, (1, 100), 25, 1.0, 0.5, False),  # ragged up to 100 densities: four chunks, some of them empty
+    (911, 6, 130, 12, 1.0, 0.5, False),     # 130 densities: not eligible -> exact kernel, same bits
     (908, 16, 4, 47, 1.0, 0.5, False),      # dim 47: not eligible either
 ])
 def test_prefilter_scores_are_bit_identical(tmp_path, oracle_lib, seed, S, M, D, scale, var_floor, dup):
