@@ -33,7 +33,7 @@
 #include "kernels.h"
 
 #ifndef SR_P16_NB
-#define SR_P16_NB 2   // 16-frame column blocks per wave in the fp16 prefilter
+#define SR_P16_NB 4   // 16-frame column blocks per wave in the fp16 prefilter (4: 256 frames per workgroup, 2 waves/SIMD)
 #endif
 
 namespace srgpu {
@@ -197,14 +197,16 @@ __global__ __launch_bounds__(kPWaves * 64, 3) void gmm_prefilter_kernel(GmmPrefi
     const float2 nk = reinterpret_cast<const float2*>(a.grp_anorm)[4u * grp + g];
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
+      // v_min3_f32 directly: the hardware minimum already drops (quiet) NaNs; fminf() would canonicalise every operand
+      // first (one v_max_f32 each).  Should a NaN survive, the limit is NaN and every density stays a candidate.
       float amin = __builtin_huge_valf();
 #pragma unroll
       for (int j = 0; j < kGroupBlocks; j++) {
-        amin = __builtin_fminf(amin, __builtin_fminf(ap[nb][j][0], ap[nb][j][1]));  // v_min3_f32; fminf drops NaNs
-        amin = __builtin_fminf(amin, __builtin_fminf(ap[nb][j][2], ap[nb][j][3]));
+        asm("v_min3_f32 %0, %0, %1, %2" : "+v"(amin) : "v"(ap[nb][j][0]), "v"(ap[nb][j][1]));
+        asm("v_min3_f32 %0, %0, %1, %2" : "+v"(amin) : "v"(ap[nb][j][2]), "v"(ap[nb][j][3]));
       }
-      if (a.chunks >= 2) amin = __builtin_fminf(amin, __shfl_xor(amin, 16));  // the other chunk(s) of the same state
-      if (a.chunks >= 4) amin = __builtin_fminf(amin, __shfl_xor(amin, 32));
+      if (a.chunks >= 2) { const float o = __shfl_xor(amin, 16); asm("v_min_f32 %0, %0, %1" : "+v"(amin) : "v"(o)); }  // the other chunk(s) of the state
+      if (a.chunks >= 4) { const float o = __shfl_xor(amin, 32); asm("v_min_f32 %0, %0, %1" : "+v"(amin) : "v"(o)); }
       const float limit = amin + 2.0f * ((kKappa * 1.001f) * nk.x * bnorm[nb] + kKonst * nk.y);
       // mask = 2*mask + !(value > limit), densities in descending order: one compare + one add-with-carry per density.
       // NaN (bad variance) or an infinite limit: stay candidates.
@@ -359,14 +361,16 @@ __global__ __launch_bounds__(kPWaves * 64, (NB <= 2 ? 3 : 2)) void gmm_prefilter
     const float2 nk = reinterpret_cast<const float2*>(a.grp_anorm)[4u * grp + g];  // sA |a|, sA |konst| (rounded up)
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
+      // v_min3_f32 directly: the hardware minimum already drops (quiet) NaNs; fminf() would canonicalise every operand
+      // first (one v_max_f32 each).  Should a NaN survive, the limit is NaN and every density stays a candidate.
       float amin = __builtin_huge_valf();
 #pragma unroll
       for (int j = 0; j < kGroupBlocks; j++) {
-        amin = __builtin_fminf(amin, __builtin_fminf(ap[nb][j][0], ap[nb][j][1]));  // v_min3_f32; fminf drops NaNs
-        amin = __builtin_fminf(amin, __builtin_fminf(ap[nb][j][2], ap[nb][j][3]));
+        asm("v_min3_f32 %0, %0, %1, %2" : "+v"(amin) : "v"(ap[nb][j][0]), "v"(ap[nb][j][1]));
+        asm("v_min3_f32 %0, %0, %1, %2" : "+v"(amin) : "v"(ap[nb][j][2]), "v"(ap[nb][j][3]));
       }
-      if (a.chunks >= 2) amin = __builtin_fminf(amin, __shfl_xor(amin, 16));  // the other chunk(s) of the same state
-      if (a.chunks >= 4) amin = __builtin_fminf(amin, __shfl_xor(amin, 32));
+      if (a.chunks >= 2) { const float o = __shfl_xor(amin, 16); asm("v_min_f32 %0, %0, %1" : "+v"(amin) : "v"(o)); }  // the other chunk(s) of the state
+      if (a.chunks >= 4) { const float o = __shfl_xor(amin, 32); asm("v_min_f32 %0, %0, %1" : "+v"(amin) : "v"(o)); }
       const float limit = amin + 2.0f * (kKappa16 * nk.x * bnorm[nb] + kKonst16 * nk.y + kAbs16 * (bnorm[nb] + nk.x));
       uint32_t mask = 0;
 #pragma unroll
