@@ -89,6 +89,9 @@ def _lib():
         C.c_double, _u16p,
     ]
     L.orc_edit_distance.argtypes = [_u64p, C.c_size_t, _u64p, C.c_size_t, _u16p]
+    L.orc_bigram_decode.restype = C.c_size_t
+    L.orc_bigram_decode.argtypes = [_f64p, C.c_size_t, C.c_size_t, C.c_uint32, C.c_uint32, _u32p, _u16p, _f32p, _f32p,
+                                    C.c_float, C.c_float, _u32p, _f32p, _u32p, C.c_size_t, _u64p]
     L.orc_accumulate.argtypes = [C.c_void_p, _f32p, C.c_size_t, _u16p, C.c_int, C.c_int, _f64p, _f64p, _f64p, _f64p]
     L.orc_recognize_batch.restype = C.c_double
     L.orc_recognize_batch.argtypes = [
@@ -318,3 +321,29 @@ class Reference:
         out = np.zeros(feats.shape[0], dtype=np.uint16)
         cost = self.L.ref_align_pruned(self.h, feats, feats.shape[0], ref, len(ref), float(threshold), out)
         return out, cost
+
+
+FLT_MAX = float(np.finfo(np.float32).max)
+
+
+def bigram_decode(dense, word_off, mixtures, silence, lm, tdp, acoustic_pruning=FLT_MAX, lm_pruning=FLT_MAX, stats=False):
+    """Teaching::LinearSearch restated (oracle/sr_oracle.c, PARITY UNPINNED): dense [T x S] f64 scores, linear lexicon
+    (word_off [W+1], mixtures = emission state per position), lm [W x W] f32 (-log p(w|h) at [w, h]),
+    tdp [2 x 4] f32 ([isSilence][loop, forward, skip, exit]).  -> (words u32[], scores f32[], times u32[])"""
+    L = _lib()
+    dense = np.ascontiguousarray(dense, dtype=np.float64)
+    T, ld = dense.shape
+    word_off = np.ascontiguousarray(word_off, dtype=np.uint32)
+    mixtures = np.ascontiguousarray(mixtures, dtype=np.uint16)
+    W = len(word_off) - 1
+    lm = np.ascontiguousarray(lm, dtype=np.float32)
+    assert lm.shape == (W, W)
+    tdp = np.ascontiguousarray(tdp, dtype=np.float32)
+    assert tdp.shape == (2, 4)
+    cap = T + 1
+    ow, osc, ot = np.zeros(cap, np.uint32), np.zeros(cap, np.float32), np.zeros(cap, np.uint32)
+    st = np.zeros(4, np.uint64)
+    n = L.orc_bigram_decode(dense, ld, T, W, silence, word_off, mixtures, lm, tdp, acoustic_pruning, lm_pruning, ow, osc, ot, cap, st)
+    assert n <= cap
+    res = (ow[:n].copy(), osc[:n].copy(), ot[:n].copy())
+    return res + (st,) if stats else res

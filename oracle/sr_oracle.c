@@ -577,3 +577,222 @@ double orc_recognize_batch(const orc_model* m, const orc_lexicon* lex, const orc
   free(counts);
   return t1 - t0;
 }
+
+/* ---- B1: bigram linear-lexicon beam search ---------------------------------------------------------------------
+ * Restates Teaching::LinearSearch (rwth-asr-0.5/src/Teaching/LinearSearch.cc).  Containers become growing arrays;
+ * BookKeeping's mark-and-sweep (BookKeeping.cc:23-47, every 50 frames) only recycles entries no live hypothesis can
+ * reach, so an append-only book yields the same traceback items (indices differ, contents do not). */
+#include <float.h>
+
+typedef struct { uint32_t word; float score; uint32_t bp; } bg_wb;                 /* WordBoundaryHypothesis :27-43 (.hh) */
+typedef struct { uint16_t state; float score; uint32_t bp; } bg_sh;                /* StateHypothesis :10-21 */
+typedef struct { uint32_t word, begin, end, entry; } bg_wh;                        /* WordHypothesis :23-38 */
+typedef struct { uint32_t word; float score; uint32_t bp, time; } bg_entry;        /* BookKeeping::Entry */
+#define BG_INVALID 0xFFFFFFFFu
+
+typedef struct {
+  uint32_t W, silence;
+  const uint32_t* word_off; const uint16_t* mixtures;
+  bg_sh *sh, *nsh; size_t n_sh, n_nsh, cap_sh;
+  bg_wh* wh; size_t n_wh, cap_wh;
+  uint32_t* sh_map;   /* stateHypothesisMap_ [maxlen + 1] */
+  uint32_t* wh_map;   /* wordHypothesisMap_ [2W] */
+  bg_entry* book; size_t n_book, cap_book;
+  float tdp[2][4];
+  uint32_t first_new;
+  float best;
+} bg_space;
+
+static uint32_t bg_map_copy(const bg_space* s, uint32_t w) { return w == s->silence ? w : w % s->W; }      /* :197-200 */
+static uint32_t bg_sil_copy(const bg_space* s, uint32_t w) { return w == s->silence ? w : w + s->W; }      /* :202-205 */
+static uint32_t bg_ac_word(const bg_space* s, uint32_t w) { return w < s->W ? w : s->silence; }           /* :207-210 */
+static int bg_is_sil(const bg_space* s, uint32_t w) { return w == s->silence || w >= s->W; }              /* :212-215 */
+static uint32_t bg_len(const bg_space* s, uint32_t w) { uint32_t a = bg_ac_word(s, w); return s->word_off[a + 1] - s->word_off[a]; }
+
+static void bg_push_sh(bg_sh** v, size_t* n, size_t* cap, bg_sh h) {
+  if (*n == *cap) { *cap = *cap ? 2 * *cap : 1024; *v = (bg_sh*)realloc(*v, *cap * sizeof(bg_sh)); }
+  (*v)[(*n)++] = h;
+}
+
+static uint32_t bg_add_entry(bg_space* s, uint32_t word, float score, uint32_t bp, uint32_t t) {  /* BookKeeping::addEntry */
+  if (s->n_book == s->cap_book) { s->cap_book *= 2; s->book = (bg_entry*)realloc(s->book, s->cap_book * sizeof(bg_entry)); }
+  bg_entry e = {word, score, bp, t};
+  s->book[s->n_book] = e;
+  return (uint32_t)s->n_book++;
+}
+
+/* addBookKeepingEntries :397-418 (tagActiveEntries omitted, see above) */
+static void bg_book_keeping(bg_space* s, uint32_t t, bg_wb* we, size_t n_we) {
+  for (size_t i = 0; i < n_we; i++) {
+    const uint32_t nb = bg_add_entry(s, bg_ac_word(s, we[i].word), we[i].score, we[i].bp, t);
+    we[i].bp = nb;
+    if (t == 0) s->book[nb].bp = nb;  /* self loop */
+    if (we[i].word == s->silence) {   /* avoid chains of silence */
+      bg_entry* cur = &s->book[nb];
+      if (s->book[cur->bp].word == s->silence) cur->bp = s->book[cur->bp].bp;
+    }
+  }
+}
+
+/* expandState :296-326 */
+static void bg_expand_state(bg_space* s, uint32_t word, bg_sh h, size_t* cap_nsh) {
+  const uint32_t n = bg_len(s, word);
+  uint32_t hi = (uint32_t)h.state + 2u;
+  if (hi > n) hi = n;
+  for (uint32_t succ = h.state > 1 ? h.state : 1; succ <= hi; succ++) {
+    float ns = h.score;
+    const uint32_t td = succ - h.state;
+    if (h.state || td > 1) ns += s->tdp[bg_is_sil(s, word)][td];
+    const uint32_t idx = s->sh_map[succ];
+    if (idx < s->first_new || idx >= s->n_nsh || s->nsh[idx].state != succ) {
+      s->sh_map[succ] = (uint32_t)s->n_nsh;
+      bg_sh nh = {(uint16_t)succ, ns, h.bp};
+      bg_push_sh(&s->nsh, &s->n_nsh, cap_nsh, nh);
+    } else if (s->nsh[idx].score >= ns) {
+      s->nsh[idx].score = ns;
+      s->nsh[idx].bp = h.bp;
+    }
+  }
+}
+
+size_t orc_bigram_decode(const double* dense, size_t dense_stride, size_t T, uint32_t W, uint32_t silence,
+                         const uint32_t* word_off, const uint16_t* mixtures, const float* lm, const float tdp[2][4],
+                         float acoustic_pruning, float lm_pruning, uint32_t* out_word, float* out_score,
+                         uint32_t* out_time, size_t cap, uint64_t* stats) {
+  bg_space sp;
+  memset(&sp, 0, sizeof(sp));
+  sp.W = W; sp.silence = silence; sp.word_off = word_off; sp.mixtures = mixtures;
+  memcpy(sp.tdp, tdp, sizeof(sp.tdp));
+  uint32_t maxlen = 0;
+  for (uint32_t w = 0; w < W; w++) if (word_off[w + 1] - word_off[w] > maxlen) maxlen = word_off[w + 1] - word_off[w];
+  sp.sh_map = (uint32_t*)malloc((maxlen + 1) * sizeof(uint32_t));
+  sp.wh_map = (uint32_t*)malloc(2 * (size_t)W * sizeof(uint32_t));
+  for (uint32_t i = 0; i <= maxlen; i++) sp.sh_map[i] = BG_INVALID;   /* reset :182-192 */
+  for (uint32_t i = 0; i < 2 * W; i++) sp.wh_map[i] = BG_INVALID;
+  size_t cap_nsh = 0;
+  sp.cap_wh = 2 * (size_t)W; sp.wh = (bg_wh*)malloc(sp.cap_wh * sizeof(bg_wh));
+  sp.cap_book = 1024; sp.book = (bg_entry*)malloc(sp.cap_book * sizeof(bg_entry));
+  { bg_entry e0 = {BG_INVALID, FLT_MAX, 0, 0}; sp.book[0] = e0; sp.n_book = 1; }   /* index 0: the sentinel (BookKeeping.cc:6,12) */
+  sp.best = FLT_MAX;
+  bg_wb* we = (bg_wb*)malloc((2 * (size_t)W + 1) * sizeof(bg_wb));
+  bg_wb* ws = (bg_wb*)malloc((2 * (size_t)W + 1) * sizeof(bg_wb));
+  size_t n_we = 0, n_ws = 0;
+  uint32_t* first_idx = (uint32_t*)malloc((size_t)W * sizeof(uint32_t));
+  if (stats) stats[0] = stats[1] = stats[2] = stats[3] = 0;
+
+  /* initialize: addInitialHypothesis :211-216 */
+  { bg_wb w0 = {silence, 0.0f, 0}; we[n_we++] = w0; }
+  bg_book_keeping(&sp, 0, we, n_we);
+
+  for (size_t t = 1; t <= T; t++) {   /* processFrame(t), t = 1..T (SearchInterface.hh:58-60) */
+    const double* row = dense + (t - 1) * dense_stride;
+    /* bigramRecombination :219-244 */
+    n_ws = W;
+    for (uint32_t w = 0; w < W; w++) { bg_wb d = {BG_INVALID, FLT_MAX, BG_INVALID}; ws[w] = d; }
+    for (size_t e = 0; e < n_we; e++) {
+      const uint32_t prev = bg_map_copy(&sp, we[e].word);
+      for (uint32_t w = 0; w < W; w++) {
+        if (w == silence) continue;
+        const float ns = we[e].score + lm[(size_t)w * W + prev];
+        if (ns < ws[w].score) { bg_wb h = {w, ns, we[e].bp}; ws[w] = h; }
+      }
+      if (we[e].word < W) { bg_wb h = {bg_sil_copy(&sp, we[e].word), we[e].score, we[e].bp}; ws[n_ws++] = h; }
+    }
+    /* LM beam :498-503 (std::min_element: first minimum; only its score is used) */
+    float best_start = ws[0].score;
+    for (size_t i = 1; i < n_ws; i++) if (ws[i].score < best_start) best_start = ws[i].score;
+    float lm_thr = lm_pruning;
+    if (lm_thr < FLT_MAX) lm_thr += best_start;
+    /* insertWordStartHypotheses :246-255 + addEntryStateHypothesis :257-268 */
+    for (size_t i = 0; i < n_ws; i++) {
+      if (!(ws[i].score < lm_thr)) continue;
+      const uint32_t word = ws[i].word;
+      if (sp.wh_map[word] == BG_INVALID) {
+        sp.wh_map[word] = (uint32_t)sp.n_wh;
+        bg_wh nh = {word, BG_INVALID, BG_INVALID, BG_INVALID};
+        sp.wh[sp.n_wh++] = nh;
+      }
+      sp.wh[sp.wh_map[word]].entry = (uint32_t)sp.n_sh;
+      bg_sh eh = {0, ws[i].score, ws[i].bp};
+      bg_push_sh(&sp.sh, &sp.n_sh, &sp.cap_sh, eh);
+    }
+    /* expandHypotheses :270-294 */
+    sp.n_nsh = 0;
+    for (size_t w = 0; w < sp.n_wh; w++) {
+      bg_wh* wh = &sp.wh[w];
+      sp.first_new = (uint32_t)sp.n_nsh;
+      if (wh->entry != BG_INVALID) { bg_expand_state(&sp, wh->word, sp.sh[wh->entry], &cap_nsh); wh->entry = BG_INVALID; }
+      /* (a freshly activated word has begin = end = invalidIndex: the loop below does not run) */
+      for (uint32_t i = wh->begin; i < wh->end; i++) bg_expand_state(&sp, wh->word, sp.sh[i], &cap_nsh);
+      wh->begin = sp.first_new;
+      wh->end = (uint32_t)sp.n_nsh;
+    }
+    { bg_sh* tmp = sp.sh; sp.sh = sp.nsh; sp.nsh = tmp; size_t c = sp.cap_sh; sp.cap_sh = cap_nsh; cap_nsh = c; sp.n_sh = sp.n_nsh; }
+    /* addAcousticScores :328-339 */
+    sp.best = FLT_MAX;
+    for (size_t w = 0; w < sp.n_wh; w++) {
+      const uint32_t a = bg_ac_word(&sp, sp.wh[w].word);
+      for (uint32_t i = sp.wh[w].begin; i < sp.wh[w].end; i++) {
+        sp.sh[i].score += (float)row[mixtures[word_off[a] + sp.sh[i].state - 1]];
+        if (sp.sh[i].score < sp.best) sp.best = sp.sh[i].score;
+      }
+    }
+    float ac_thr = acoustic_pruning;
+    if (ac_thr < FLT_MAX) ac_thr += sp.best;
+    /* pruneStatesAndFindWordEnds :341-376 */
+    n_we = 0;
+    {
+      size_t in = 0, out = 0, wout = 0;
+      for (size_t w = 0; w < sp.n_wh; w++) {
+        bg_wh* wh = &sp.wh[w];
+        const uint32_t end = wh->end;
+        wh->begin = (uint32_t)out;
+        const uint32_t n = bg_len(&sp, wh->word);
+        for (; in < end; in++) {
+          const float sc = sp.sh[in].score + sp.tdp[bg_is_sil(&sp, wh->word)][3];
+          if (sc < ac_thr) {
+            sp.sh[out++] = sp.sh[in];
+            if (sp.sh[in].state == n) { bg_wb h = {wh->word, sc, sp.sh[in].bp}; we[n_we++] = h; }
+          }
+        }
+        wh->end = (uint32_t)out;
+        if (wh->end - wh->begin > 0) { sp.wh_map[wh->word] = (uint32_t)wout; sp.wh[wout++] = *wh; }
+        else sp.wh_map[wh->word] = BG_INVALID;
+      }
+      sp.n_wh = wout;
+      sp.n_sh = out;
+    }
+    /* mergeSilenceToBigramNodes :378-395 -- including its quirk: the merged hypotheses sit at the index of their
+     * first occurrence, but the list is then cut to its first nWordEnds entries */
+    {
+      for (uint32_t w = 0; w < W; w++) first_idx[w] = BG_INVALID;
+      size_t n_ends = 0;
+      for (size_t e = 0; e < n_we; e++) {
+        const uint32_t word = bg_map_copy(&sp, we[e].word);
+        if (first_idx[word] == BG_INVALID) { first_idx[word] = (uint32_t)e; n_ends++; }
+        const uint32_t wi = first_idx[word];
+        if (we[e].score <= we[wi].score) we[wi] = we[e];
+      }
+      n_we = n_ends;
+    }
+    bg_book_keeping(&sp, (uint32_t)t, we, n_we);
+    if (stats) { stats[0] += n_we; stats[1] += sp.n_wh; stats[2] += sp.n_sh; stats[3] = sp.n_book; }
+  }
+
+  /* traceback :420-436 */
+  size_t n_out = 0;
+  if (n_we > 0) {
+    size_t bi = 0;
+    for (size_t i = 1; i < n_we; i++) if (we[i].score < we[bi].score) bi = i;
+    uint32_t bp = we[bi].bp;
+    size_t len = 0;
+    for (uint32_t b = bp; sp.book[b].time > 0; b = sp.book[b].bp) len++;
+    n_out = len;
+    for (uint32_t b = bp; sp.book[b].time > 0; b = sp.book[b].bp) {
+      len--;
+      if (len < cap) { out_word[len] = sp.book[b].word; out_score[len] = sp.book[b].score; out_time[len] = sp.book[b].time; }
+    }
+  }
+  free(sp.sh); free(sp.nsh); free(sp.wh); free(sp.sh_map); free(sp.wh_map); free(sp.book); free(we); free(ws); free(first_idx);
+  return n_out;
+}

@@ -126,6 +126,22 @@ double orc_recognize_batch(const orc_model* m, const orc_lexicon* lex, const orc
                            size_t n_utts, uint32_t dim, int n_threads,
                            uint32_t* out_words, uint64_t* out_word_off);
 
+/* ---- B1: bigram linear-lexicon beam search (rwth-asr-0.5/src/Teaching/LinearSearch.cc) ------------------------
+ * PARITY UNPINNED: the RWTH toolkit cannot be built here and holds no fixtures for this decoder, so this
+ * restatement -- written line by line after LinearSearch.cc:211-436,496-515 and BookKeeping.cc -- is the only
+ * specification the GPU kernel is tested against.
+ * Scores are float (Teaching/Types.hh:17).  words 0..W-1 (one of them `silence`); slot w+W is the silence copy entered
+ * after word w.  word_off[W+1]/mixtures[]: the linear lexicon (mixture = emission state per position);
+ * lm[w*W + h] = -log p(w | h); tdp[isSilence][0..2] loop/forward/skip, tdp[isSilence][3] exit penalty
+ * (SearchSpace::setTransitionScores :169-180).  am scores: (float)dense[t*stride + mixture].
+ * Pruning thresholds >= FLT_MAX switch the beam off (:445-455,499-510).
+ * Output: the traceback items (word, score, time) of LinearSearch::getResult; returns their number (written up to
+ * `cap`).  stats (optional, [4]): sum over frames of word ends after merging, active words, state hyps, book entries. */
+size_t orc_bigram_decode(const double* dense, size_t dense_stride, size_t T, uint32_t W, uint32_t silence,
+                         const uint32_t* word_off, const uint16_t* mixtures, const float* lm, const float tdp[2][4],
+                         float acoustic_pruning, float lm_pruning, uint32_t* out_word, float* out_score,
+                         uint32_t* out_time, size_t cap, uint64_t* stats);
+
 #ifdef __cplusplus
 }
 #endif
