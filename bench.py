@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--kernel", choices=["mfma", "exact", "prefilter"], default="prefilter",
                     help="GMM scoring path: prefilter (fp16 MFMA candidate pass + exact FP64 refinement, bit-exact scores), "
                          "mfma (dense FP64 MFMA, ~1e-15), exact (dense FP64 VALU, bit-exact)")
+    ap.add_argument("--decoder", choices=["zerogram", "bigram"], default="zerogram",
+                    help="zerogram: Recognizer::recognizeSequence_pruned (the headline config); bigram: Teaching::LinearSearch "
+                         "with a seeded dense bigram table (BASELINE configs[4]: use --words 2666 --mix 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals "
                     "where several ranks share one GPU)")
@@ -91,7 +94,23 @@ def main():
     lexh = model.lexicon(word_off, automaton, lex.silence_idx, tdp, sil_state)
     corpus = model.upload(feats, frame_off)  # inputs resident in HBM before timing starts
 
+    bg = None
+    if args.decoder == "bigram":
+        # dense bigram table: rows of p(. | h) from a symmetric Dirichlet(1), scale 1; transition scores of
+        # the reference's example set-up (example-setup/config/recognition-triphones-lda-pruned.config:46-57)
+        lm_rng = np.random.default_rng(99)
+        nW = lex.n_words
+        lm = np.empty((nW, nW), np.float32)
+        for h0 in range(0, nW, 256):
+            p = lm_rng.dirichlet(np.ones(nW), size=min(256, nW - h0))
+            lm[:, h0:h0 + p.shape[0]] = (-np.log(np.maximum(p, 1e-30))).T
+        bg_tdp = np.array([[3.0, 0.0, 3.0, 150.0], [0.0001, 3.0, np.inf, 15.0]], np.float32)
+        bg = model.bigram(word_off, automaton, lex.silence_idx, lm, bg_tdp)
+
     def step():
+        if bg is not None:
+            w, _, _, off = corpus.recognize_bigram(bg, args.beam, capi.FLT_MAX, kernel)
+            return w, off
         return corpus.recognize(lexh, args.beam, wp, kernel)
 
     def fence():
@@ -154,12 +173,23 @@ def main():
         }
         if args.kernel == "prefilter":
             out.update(prefilter_report(args, prof, n_frames, D, S))
+        if bg is not None:
+            out["config"]["workload"] = out["config"]["workload"].replace("beam Viterbi", "bigram linear-lexicon beam search "
+                                                                          "(Teaching::LinearSearch, parity unpinned)")
+            out["search"]["kernel"] = "bigram_kernel"
+            out["search"].pop("achieved_GBps", None)
+            out["search"].pop("bytes_per_frame", None)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, mixset_path, lex, tdp, wp, feats, frame_off, words, woff)
+            if bg is not None:
+                out["cpu_baseline"] = cpu_baseline_bigram(args, mixset_path, lex, lm, bg_tdp, feats, frame_off, words, woff)
+            else:
+                out["cpu_baseline"] = cpu_baseline(args, mixset_path, lex, tdp, wp, feats, frame_off, words, woff)
         print(json.dumps(out))
         sys.stdout.flush()
 
     corpus.close()
+    if bg is not None:
+        bg.close()
     lexh.close()
     model.close()
     if distributed:
@@ -280,6 +310,34 @@ def cpu_baseline(args, mixset_path, lex, tdp, wp, feats, frame_off, gpu_words, g
                   f"OpenMP schedule(dynamic) over utterances, {secs:.1f} s wall",
         "words_match_gpu": match,
     }
+
+
+def cpu_baseline_bigram(args, mixset_path, lex, lm, bg_tdp, feats, frame_off, gpu_words, gpu_woff):
+    """Dense scoring (OpenMP over frames) + the bigram search restatement on the shortest utterances that fit the CPU
+    budget; words checked against the GPU's."""
+    from oracle import pyoracle
+
+    cores = usable_cores()
+    orc = pyoracle.Oracle(mixset_path, 39, lex)
+    word_off, mixtures, _ = lex.flatten()
+    lens = np.diff(frame_off.astype(np.int64))
+    order = np.argsort(lens, kind="stable")
+    t0 = time.perf_counter()
+    done, frames, match = 0, 0, True
+    for u in order:
+        x = feats[int(frame_off[u]):int(frame_off[u + 1])]
+        dense = orc.score_matrix(x, n_threads=cores)
+        w, _, _ = pyoracle.bigram_decode(dense, word_off, mixtures, lex.silence_idx, lm, bg_tdp, args.beam, pyoracle.FLT_MAX)
+        match = match and bool(np.array_equal(w, gpu_words[int(gpu_woff[u]):int(gpu_woff[u + 1])]))
+        done += 1
+        frames += len(x)
+        if time.perf_counter() - t0 > args.cpu_seconds:
+            break
+    secs = time.perf_counter() - t0
+    orc.close()
+    return {"value": frames / secs, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{done} shortest of {len(lens)} utterances ({frames} frames), dense scoring on {cores} threads + "
+                      f"sequential bigram search, {secs:.1f} s wall", "words_match_gpu": match}
 
 
 if __name__ == "__main__":

@@ -164,6 +164,29 @@ SR_API int sr_model_tying_info(const sr_model* m, uint32_t* n_mean, uint32_t* n_
 SR_API int sr_accumulate_corpus(sr_model* m, sr_corpus* c, const uint16_t* states, int first_pass, int max_approx,
                                 double* mean_acc, double* mean_w, double* var_acc, double* var_w);
 
+/* ---- bigram-LM beam search over a linear lexicon ---------------------------------------------------------------
+ * Replaces Teaching::LinearSearch (rwth-asr-0.5/src/Teaching/LinearSearch.cc: initialize :489-495, processFrame
+ * :496-515, getResult :517-520) for a whole corpus.  Scores are float there (Teaching/Types.hh:17); the acoustic
+ * score of mixture m at frame t is (float) of this library's FP64 score.
+ *   word_off[W+1], mixtures[]: the linear lexicon (LinearSearch::buildLinearLexicon :477-483), mixture = emission state;
+ *   lm[w*W + h] = -log p(w | h) (SearchInterface::getLanguageModelScore(w, h), SearchInterface.cc:77-81);
+ *   tdp[8] = [isSilence][loop, forward, skip, exit] (SearchSpace::setTransitionScores :169-180).
+ * PARITY UNPINNED: checked against the CPU restatement under oracle/ only (the toolkit cannot be built here). */
+typedef struct sr_bigram sr_bigram;
+typedef struct {
+  float acoustic_pruning;   /* "acoustic-pruning" (:441-442); >= FLT_MAX: off */
+  float lm_pruning;         /* "lm-pruning" (:444-445) */
+  int gmm_kernel;
+  uint32_t max_word_ends;   /* traceback book capacity per frame and utterance; 0 = W (cannot overflow) */
+} sr_bigram_params;
+SR_API int sr_bigram_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, const uint16_t* mixtures,
+                            uint32_t silence_word, const float* lm, const float tdp[8], sr_bigram** out);
+SR_API int sr_bigram_destroy(sr_bigram* b);
+/* out_word/out_score/out_time: capacity n_frames + n_utts (LinearSearch::getResult's traceback items, silence included);
+ * out_off[n_utts+1]: items of utterance u are [out_off[u], out_off[u+1]).  SR_ELIMIT if a book overflowed. */
+SR_API int sr_recognize_bigram_corpus(sr_model* m, sr_corpus* c, sr_bigram* b, const sr_bigram_params* p,
+                                      uint32_t* out_word, float* out_score, uint32_t* out_time, uint64_t* out_off);
+
 /* ---- measurement --------------------------------------------------------------------------------
  * When enabled, every kernel launch of this model handle is bracketed by HIP events on the
  * launch stream; sr_profile_read() synchronises and returns accumulated device times. */

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsrgpu.so")
-SOURCES = ["srgpu_api.cpp", "mixset.cpp", "gmm_mfma.hip", "gmm_exact.hip", "gmm_prefilter.hip", "viterbi_decode.hip", "viterbi_fast.hip", "viterbi_align.hip", "em_accumulate.hip"]
+SOURCES = ["srgpu_api.cpp", "mixset.cpp", "gmm_mfma.hip", "gmm_exact.hip", "gmm_prefilter.hip", "viterbi_decode.hip", "viterbi_fast.hip", "viterbi_align.hip", "viterbi_bigram.hip", "em_accumulate.hip"]
 HEADERS = ["kernels.h", "host_util.h", os.path.join("..", "..", "include", "srgpu.h")]
 FLAGS = (["-DSR_DECODE_STAMPS"] if __import__("os").environ.get("SR_DECODE_STAMPS") else []) + ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 # gmm_exact.hip must not contract a*b+c into an FMA: it replays the reference's SSE2 operation order

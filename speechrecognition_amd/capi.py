@@ -23,6 +23,7 @@ SYMBOLS = [
     "sr_last_error", "sr_device_count", "sr_model_create", "sr_model_load_mixset", "sr_model_destroy", "sr_model_info",
     "sr_corpus_upload", "sr_corpus_destroy", "sr_score_corpus", "sr_score_frames", "sr_lexicon_create",
     "sr_lexicon_destroy", "sr_recognize_corpus", "sr_recognize_batch", "sr_align_corpus", "sr_align_corpus_pruned", "sr_path_scores_corpus", "sr_model_create_from_statistics", "sr_mixset_write", "sr_model_set_tying", "sr_model_tying_info", "sr_accumulate_corpus",
+    "sr_bigram_create", "sr_bigram_destroy", "sr_recognize_bigram_corpus",
     "sr_profile_enable", "sr_profile_reset", "sr_profile_read",
 ]
 
@@ -35,6 +36,10 @@ class SrError(RuntimeError):
 
 class SearchParams(C.Structure):
     _fields_ = [("am_threshold", C.c_double), ("word_penalty", C.c_double), ("gmm_kernel", C.c_int), ("reserved", C.c_int)]
+
+
+class BigramParams(C.Structure):
+    _fields_ = [("acoustic_pruning", C.c_float), ("lm_pruning", C.c_float), ("gmm_kernel", C.c_int), ("max_word_ends", C.c_uint32)]
 
 
 class Profile(C.Structure):
@@ -77,6 +82,9 @@ def lib():
         L.sr_model_set_tying.argtypes = [vp, u32, u32, vp, vp]
         L.sr_model_tying_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
         L.sr_accumulate_corpus.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp]
+        L.sr_bigram_create.argtypes = [vp, u32, vp, vp, u32, vp, vp, C.POINTER(vp)]
+        L.sr_bigram_destroy.argtypes = [vp]
+        L.sr_recognize_bigram_corpus.argtypes = [vp, vp, vp, C.POINTER(BigramParams), vp, vp, vp, vp]
         L.sr_profile_enable.argtypes = [vp, i32]
         L.sr_profile_reset.argtypes = [vp]
         L.sr_profile_read.argtypes = [vp, C.POINTER(Profile)]
@@ -161,6 +169,9 @@ class Model:
     def lexicon(self, word_off, automaton, silence_idx, tdp, silence_state):
         return Lexicon(self, word_off, automaton, silence_idx, tdp, silence_state)
 
+    def bigram(self, word_off, mixtures, silence_word, lm, tdp):
+        return Bigram(self, word_off, mixtures, silence_word, lm, tdp)
+
     # -- profiling ---------------------------------------------------------------------------------
     def profile(self, on=True):
         _check(lib().sr_profile_enable(self.h, int(on)))
@@ -170,6 +181,30 @@ class Model:
         p = Profile()
         _check(lib().sr_profile_read(self.h, C.byref(p)))
         return {k: getattr(p, k) for k, _ in Profile._fields_}
+
+
+FLT_MAX = float(np.finfo(np.float32).max)
+
+
+class Bigram:
+    """sr_bigram handle: linear lexicon + dense bigram table + transition scores (Teaching::LinearSearch)."""
+
+    def __init__(self, model, word_off, mixtures, silence_word, lm, tdp):
+        self.model = model
+        word_off = np.ascontiguousarray(word_off, dtype=np.uint32)
+        mixtures = np.ascontiguousarray(mixtures, dtype=np.uint16)
+        W = len(word_off) - 1
+        lm = np.ascontiguousarray(lm, dtype=np.float32)
+        assert lm.shape == (W, W)
+        tdp = np.ascontiguousarray(tdp, dtype=np.float32)
+        assert tdp.size == 8
+        self.h = C.c_void_p()
+        _check(lib().sr_bigram_create(model.h, W, _ptr(word_off), _ptr(mixtures), silence_word, _ptr(lm), _ptr(tdp), C.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            lib().sr_bigram_destroy(self.h)
+            self.h = None
 
 
 class Corpus:
@@ -240,6 +275,16 @@ class Corpus:
         _check(lib().sr_accumulate_corpus(self.model.h, self.h, _ptr(states), int(first_pass), int(max_approx), _ptr(ma), _ptr(mw),
                                           _ptr(va), _ptr(vw)))
         return ma, mw, va, vw
+
+    def recognize_bigram(self, bigram, acoustic_pruning=FLT_MAX, lm_pruning=FLT_MAX, kernel=GMM_PREFILTER, max_word_ends=0):
+        """-> (words u32[], scores f32[], times u32[], off u64[n_utts+1]): LinearSearch::getResult per utterance"""
+        cap = max(self.n_frames + self.n_utts, 1)
+        ow, osc, ot = np.zeros(cap, np.uint32), np.zeros(cap, np.float32), np.zeros(cap, np.uint32)
+        off = np.zeros(self.n_utts + 1, np.uint64)
+        p = BigramParams(acoustic_pruning, lm_pruning, kernel, max_word_ends)
+        _check(lib().sr_recognize_bigram_corpus(self.model.h, self.h, bigram.h, C.byref(p), _ptr(ow), _ptr(osc), _ptr(ot), _ptr(off)))
+        n = int(off[-1])
+        return ow[:n], osc[:n], ot[:n], off
 
     def path_scores(self, states, kernel=GMM_PREFILTER):
         """Emission cost along a state path (one state per frame): Trainer::calc_am_score's summands."""

@@ -139,6 +139,30 @@ hipError_t launch_align_full(const AlignArgs& a, hipStream_t stream);
 hipError_t launch_align_pruned(const AlignArgs& a, hipStream_t stream);
 uint32_t align_max_positions();
 
+// ---- bigram-LM beam search over a linear lexicon (viterbi_bigram.hip; Teaching::LinearSearch) -----------------------
+struct BigramArgs {
+  const double* scores;         // [frames x ld]
+  uint32_t ld;
+  const uint64_t* frame_off;    // [n_utts_total+1]
+  uint64_t frame_base;
+  uint32_t utt_first, n_utts;
+  uint32_t n_words, silence, n_positions;  // W; silence word; sum of state counts over the 2W slots (words + silence copies)
+  const uint32_t* slot_off;     // [2W+1] first dense position of every slot
+  const uint32_t* slot_mix;     // [2W] offset of the slot's acoustic word in `mixtures`
+  const uint16_t* mixtures;     // emission state per lexicon position
+  const float* lmT;             // [W x W] transposed: lmT[h*W + w] = -log p(w | h)
+  float tdp[2][4];              // [isSilence][loop, forward, skip, exit]
+  float ac_pruning, lm_pruning; // >= FLT_MAX: off
+  uint32_t *we_slot, *we_bp; float* we_score;  // workspace [n_utts][2][2W]
+  uint4* book;                  // traceback book; utterance u owns [book_off[u], book_off[u+1])
+  const uint64_t* book_off;     // [n_utts_total+1]
+  uint32_t* out_word; float* out_score; uint32_t* out_time;  // [frames + utts]: utterance u at frame_off[u] + u
+  uint32_t *out_count, *out_flags;  // [n_utts_total]; flag 1 = book capacity exceeded
+};
+hipError_t launch_bigram(const BigramArgs& a, hipStream_t stream);
+size_t bigram_lds_bytes(uint32_t n_words, uint32_t n_positions);
+uint32_t bigram_max_words();
+
 // out[f] = scores[(f - frame_base) * ld + states[f]] for f in [f0, f1)  (Trainer::calc_am_score, Training.cpp:605)
 hipError_t launch_path_scores(const double* scores, uint32_t ld, uint64_t frame_base, uint64_t f0, uint64_t f1,
                               const uint16_t* states, double* out, hipStream_t stream);

@@ -145,6 +145,20 @@ struct sr_lexicon {
   uint32_t f_n = 0, f_init = 0, f_init_end = 0;
 };
 
+struct sr_bigram {
+  sr_model* model = nullptr;
+  uint32_t n_words = 0, silence = 0, n_positions = 0;
+  float tdp[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  DevBuf<uint32_t> slot_off, slot_mix;
+  DevBuf<uint16_t> mixtures;
+  DevBuf<float> lmT;
+  // workspace
+  DevBuf<uint32_t> we_slot, we_bp, out_word, out_time, out_count, out_flags;
+  DevBuf<float> we_score, out_score;
+  DevBuf<uint4> book;
+  DevBuf<uint64_t> book_off;
+};
+
 namespace {
 
 // ---- model packing for the MFMA kernel ---------------------------------------------------------
@@ -884,6 +898,140 @@ int sr_recognize_corpus(sr_model* m, sr_corpus* c, sr_lexicon* l, const sr_searc
   if (tb_score) HIP_TRY(hipMemcpy(tb_score, c->tb_score.p, sizeof(double) * (F + U), hipMemcpyDeviceToHost));
   if (tb_word) HIP_TRY(hipMemcpy(tb_word, c->tb_word.p, sizeof(uint16_t) * (F + U), hipMemcpyDeviceToHost));
   if (tb_bkp) HIP_TRY(hipMemcpy(tb_bkp, c->tb_bkp.p, sizeof(uint16_t) * (F + U), hipMemcpyDeviceToHost));
+  if (m->profiling) m->prof.frames += F;
+  return SR_OK;
+}
+
+int sr_bigram_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, const uint16_t* mixtures,
+                     uint32_t silence_word, const float* lm, const float tdp[8], sr_bigram** out) {
+  if (!out) return fail(SR_EINVAL, "out is null");
+  *out = nullptr;
+  int rc = check_model(m);
+  if (rc) return rc;
+  if (!word_off || !mixtures || !lm || !tdp) return fail(SR_EINVAL, "null argument");
+  const uint32_t W = n_words;
+  if (W == 0 || silence_word >= W) return fail(SR_EINVAL, "silence word %u out of range (%u words)", silence_word, W);
+  if (W > bigram_max_words()) return fail(SR_ELIMIT, "%u words: the bigram search handles at most %u", W, bigram_max_words());
+  if (word_off[0] != 0) return fail(SR_EINVAL, "word_off[0] must be 0");
+  for (uint32_t w = 0; w < W; w++) {
+    if (word_off[w + 1] <= word_off[w]) return fail(SR_EINVAL, "word %u has no states", w);
+    for (uint32_t i = word_off[w]; i < word_off[w + 1]; i++)
+      if (mixtures[i] >= m->n_states) return fail(SR_EINVAL, "word %u: mixture %u out of range", w, mixtures[i]);
+  }
+  // slots: words 0..W-1, then the silence copy of every word (Teaching::LinearSearch: silenceCopy :202-205)
+  const uint32_t n_sil = word_off[silence_word + 1] - word_off[silence_word];
+  std::vector<uint32_t> slot_off(2 * (size_t)W + 1, 0), slot_mix(2 * (size_t)W);
+  for (uint32_t a = 0; a < 2 * W; a++) {
+    const uint32_t aw = a < W ? a : silence_word;
+    slot_off[a + 1] = slot_off[a] + (a < W ? word_off[a + 1] - word_off[a] : n_sil);
+    slot_mix[a] = word_off[aw];
+  }
+  const uint32_t P2 = slot_off[2 * W];
+  if (bigram_lds_bytes(W, P2) > 160 * 1024)
+    return fail(SR_ELIMIT, "lexicon too large for the bigram search's LDS image (%zu bytes > 160 KiB)", bigram_lds_bytes(W, P2));
+  std::vector<float> lmT((size_t)W * W);
+  for (uint32_t w = 0; w < W; w++)
+    for (uint32_t h = 0; h < W; h++) lmT[(size_t)h * W + w] = lm[(size_t)w * W + h];
+  sr_bigram* b = new sr_bigram();
+  b->model = m; b->n_words = W; b->silence = silence_word; b->n_positions = P2;
+  memcpy(b->tdp, tdp, sizeof(b->tdp));
+  hipError_t e;
+  if ((e = b->slot_off.upload(slot_off.data(), slot_off.size())) != hipSuccess ||
+      (e = b->slot_mix.upload(slot_mix.data(), slot_mix.size())) != hipSuccess ||
+      (e = b->mixtures.upload(mixtures, word_off[W])) != hipSuccess || (e = b->lmT.upload(lmT.data(), lmT.size())) != hipSuccess) {
+    sr_bigram_destroy(b);
+    return fail(SR_EHIP, "bigram upload: %s", hipGetErrorString(e));
+  }
+  *out = b;
+  return SR_OK;
+}
+
+int sr_bigram_destroy(sr_bigram* b) {
+  if (!b) return SR_OK;
+  if (b->model) { (void)hipSetDevice(b->model->device); (void)hipDeviceSynchronize(); }
+  b->slot_off.release(); b->slot_mix.release(); b->mixtures.release(); b->lmT.release();
+  b->we_slot.release(); b->we_bp.release(); b->we_score.release(); b->book.release(); b->book_off.release();
+  b->out_word.release(); b->out_time.release(); b->out_score.release(); b->out_count.release(); b->out_flags.release();
+  delete b;
+  return SR_OK;
+}
+
+int sr_recognize_bigram_corpus(sr_model* m, sr_corpus* c, sr_bigram* b, const sr_bigram_params* p, uint32_t* out_word,
+                               float* out_score, uint32_t* out_time, uint64_t* out_off) {
+  int rc = check_model(m);
+  if (rc) return rc;
+  if (!c || c->model != m) return fail(SR_EINVAL, "corpus does not belong to this model");
+  if (!b || b->model != m) return fail(SR_EINVAL, "bigram search net does not belong to this model");
+  if (!p || !out_off || ((!out_word || !out_score || !out_time) && c->n_frames)) return fail(SR_EINVAL, "null argument");
+  const uint32_t U = c->n_utts, W = b->n_words;
+  const uint64_t F = c->n_frames;
+  const std::vector<Chunk> chunks = make_chunks(c, m->chunk_frames);
+  if ((rc = ensure_score_ws(m, chunks))) return rc;
+  // traceback book: 2 start entries + (word ends kept per frame <= W) * T per utterance
+  const uint64_t per_frame = p->max_word_ends ? std::min<uint64_t>(p->max_word_ends, W) : W;
+  std::vector<uint64_t> book_off(U + 1, 0);
+  uint32_t max_chunk_utts = 0;
+  for (uint32_t u = 0; u < U; u++) book_off[u + 1] = book_off[u] + 2 + per_frame * (c->frame_off[u + 1] - c->frame_off[u]);
+  for (const Chunk& ch : chunks) max_chunk_utts = std::max(max_chunk_utts, ch.u1 - ch.u0);
+  HIP_TRY(b->book.ensure(book_off[U]));
+  HIP_TRY(b->book_off.upload(book_off.data(), book_off.size()));
+  HIP_TRY(b->we_slot.ensure((size_t)max_chunk_utts * 4 * W));
+  HIP_TRY(b->we_bp.ensure((size_t)max_chunk_utts * 4 * W));
+  HIP_TRY(b->we_score.ensure((size_t)max_chunk_utts * 4 * W));
+  HIP_TRY(b->out_word.ensure(F + U));
+  HIP_TRY(b->out_time.ensure(F + U));
+  HIP_TRY(b->out_score.ensure(F + U));
+  HIP_TRY(b->out_count.ensure(U));
+  HIP_TRY(b->out_flags.ensure(U));
+
+  BigramArgs ba{};
+  ba.ld = m->ld; ba.frame_off = c->d_frame_off.p;
+  ba.n_words = W; ba.silence = b->silence; ba.n_positions = b->n_positions;
+  ba.slot_off = b->slot_off.p; ba.slot_mix = b->slot_mix.p; ba.mixtures = b->mixtures.p; ba.lmT = b->lmT.p;
+  memcpy(ba.tdp, b->tdp, sizeof(ba.tdp));
+  ba.ac_pruning = p->acoustic_pruning; ba.lm_pruning = p->lm_pruning;
+  ba.we_slot = b->we_slot.p; ba.we_bp = b->we_bp.p; ba.we_score = b->we_score.p;
+  ba.book = b->book.p; ba.book_off = b->book_off.p;
+  ba.out_word = b->out_word.p; ba.out_score = b->out_score.p; ba.out_time = b->out_time.p;
+  ba.out_count = b->out_count.p; ba.out_flags = b->out_flags.p;
+
+  hipStream_t s_search = m->overlap ? m->s_search : m->s_gmm;
+  for (size_t i = 0; i < chunks.size(); i++) {
+    const Chunk& ch = chunks[i];
+    const int buf = (int)(i & 1);
+    if (i >= 2) HIP_TRY(hipStreamWaitEvent(m->s_gmm, m->ev_consumed[buf], 0));
+    if ((rc = launch_scoring(m, c->feats.p + ch.f0 * m->dim, ch.f1 - ch.f0, p->gmm_kernel, m->scores[buf].p))) return rc;
+    HIP_TRY(hipEventRecord(m->ev_scored[buf], m->s_gmm));
+    HIP_TRY(hipStreamWaitEvent(s_search, m->ev_scored[buf], 0));
+    ba.scores = m->scores[buf].p; ba.frame_base = ch.f0; ba.utt_first = ch.u0; ba.n_utts = ch.u1 - ch.u0;
+    EventPair ep{};
+    if ((rc = prof_begin(m, s_search, 1, &ep))) return rc;
+    HIP_TRY(launch_bigram(ba, s_search));
+    if ((rc = prof_end(m, s_search, &ep))) return rc;
+    HIP_TRY(hipEventRecord(m->ev_consumed[buf], s_search));
+    if (m->profiling) m->prof.search_bytes += 8.0 * m->n_states * (double)(ch.f1 - ch.f0);
+  }
+  HIP_TRY(hipStreamSynchronize(m->s_search));
+  HIP_TRY(hipStreamSynchronize(m->s_gmm));
+
+  std::vector<uint32_t> counts(U), flags(U), dw(F + U), dt(F + U);
+  std::vector<float> ds(F + U);
+  if (U) {
+    HIP_TRY(hipMemcpy(counts.data(), b->out_count.p, sizeof(uint32_t) * U, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(flags.data(), b->out_flags.p, sizeof(uint32_t) * U, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dw.data(), b->out_word.p, sizeof(uint32_t) * (F + U), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dt.data(), b->out_time.p, sizeof(uint32_t) * (F + U), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ds.data(), b->out_score.p, sizeof(float) * (F + U), hipMemcpyDeviceToHost));
+  }
+  uint64_t n = 0;
+  out_off[0] = 0;
+  for (uint32_t u = 0; u < U; u++) {
+    if (flags[u]) return fail(SR_ELIMIT, "utterance %u: more than %llu word ends per frame (sr_bigram_params.max_word_ends)", u,
+                              (unsigned long long)per_frame);
+    const uint64_t o = c->frame_off[u] + u;
+    for (uint32_t i = 0; i < counts[u]; i++, n++) { out_word[n] = dw[o + i]; out_score[n] = ds[o + i]; out_time[n] = dt[o + i]; }
+    out_off[u + 1] = n;
+  }
   if (m->profiling) m->prof.frames += F;
   return SR_OK;
 }

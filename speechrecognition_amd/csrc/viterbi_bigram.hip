@@ -1,0 +1,419 @@
+// viterbi_bigram.hip -- bigram-LM beam search over a linear lexicon, one workgroup per utterance.
+//
+// Follows Teaching::LinearSearch (rwth-asr-0.5/src/Teaching/LinearSearch.cc:211-436,496-515; BookKeeping.cc).
+// PARITY UNPINNED: the toolkit does not build here and holds no fixtures; the CPU restatement of the same source in
+// the test infrastructure is the specification, tests/test_bigram.py compares against it bit for bit.
+//
+// The reference keeps hypotheses in lists whose ORDER decides ties and -- through mergeSilenceToBigramNodes' cut of
+// the list to its first nWordEnds entries (:378-395) -- even which word ends survive.  The kernel therefore keeps the
+// same lists: `L` = the active word hypotheses in activation order (compacted with order-preserving prefix sums, as
+// pruneStatesAndFindWordEnds does in place), word ends emitted in that order.  State hypotheses are dense per slot
+// (word or silence copy) in LDS: a missing hypothesis is +inf, which no finite candidate loses to, so list
+// membership and "score < inf" are the same thing.
+//
+// Per frame t = 1..T:
+//   1 bigramRecombination (:219-244): thread per word w, loop over the ordered word ends (strict <: first wins); the LM
+//     table is stored transposed, lmT[h][w], so that the loop reads contiguous rows.  Silence copies take the word
+//     end's score.  LM beam (:498-503), entries that fail it are dropped.
+//   2 activation (:257-268): newly started words are appended to L in the order of the start list -- words ascending,
+//     then silence copies in word-end order (two ordered scans).
+//   3 expandHypotheses + addAcousticScores (:270-339): thread per active word, states descending in place; candidates
+//     in ascending predecessor order with >= (the later one wins ties); best score by workgroup reduction.
+//   4 pruneStatesAndFindWordEnds (:341-376): acoustic beam on score + exit penalty; ordered compaction of L, ordered
+//     word-end list.
+//   5 mergeSilenceToBigramNodes (:378-395) with its positional quirk, 6 addBookKeepingEntries (:397-418) into an
+//     append-only book (the reference's mark-and-sweep only recycles unreachable entries).
+// End: traceback from the first best word end (:420-436).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace srgpu {
+
+static constexpr int kBgThreads = 1024;
+static constexpr int kBgWaves = kBgThreads / 64;
+static constexpr int kBgStage = 256;  // word ends staged per pass of the recombination loop
+static constexpr float kFltMax = 3.402823466e+38f;
+// flags on a word end of the merged list (see step 6): the same word end also sits LATER in the list / sat EARLIER
+static constexpr uint32_t kShadowed = 0x80000000u, kRepeat = 0x40000000u, kSlotMask = 0x3FFFFFFFu;
+
+__device__ inline uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t n = __shfl_up(v, o);
+    if (lane >= o) v += n;
+  }
+  return v;
+}
+
+// exclusive prefix of `v` over the workgroup in thread order; total in *total.  `tmp` = kBgWaves + 1 words of LDS.
+__device__ inline uint32_t wg_excl_scan(uint32_t v, uint32_t* tmp, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t inc = wave_incl_scan(v, lane);
+  __syncthreads();  // tmp free
+  if (lane == 63) tmp[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int w = 0; w < kBgWaves; w++) { const uint32_t t = tmp[w]; tmp[w] = run; run += t; }
+    tmp[kBgWaves] = run;
+  }
+  __syncthreads();
+  *total = tmp[kBgWaves];
+  return tmp[wave] + inc - v;
+}
+
+__device__ inline float wg_min(float v, float* tmp) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) tmp[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = tmp[0];
+  for (int w = 1; w < kBgWaves; w++) r = fminf(r, tmp[w]);
+  return r;
+}
+
+template <int KW>  // words per thread in the recombination: W <= KW * kBgThreads
+__global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t W = a.n_words, W2 = 2 * a.n_words, P2 = a.n_positions, sil = a.silence;
+  float* st_score = reinterpret_cast<float*>(smem);           // [P2]
+  uint32_t* st_bp = reinterpret_cast<uint32_t*>(st_score + P2);  // [P2]
+  float* en_score = reinterpret_cast<float*>(st_bp + P2);     // [2W] entry (start) hypotheses; scratch in step 5
+  uint32_t* en_bp = reinterpret_cast<uint32_t*>(en_score + W2);  // [2W]
+  uint32_t* stage = en_bp + W2;                               // [3 * kBgStage]
+  uint32_t* scan_tmp = stage + 3 * kBgStage;                  // [kBgWaves + 1]
+  float* red_tmp = reinterpret_cast<float*>(scan_tmp + kBgWaves + 1);  // [kBgWaves]
+  uint16_t* L[2];
+  L[0] = reinterpret_cast<uint16_t*>(red_tmp + kBgWaves);     // [2W] active word slots, activation order
+  L[1] = L[0] + W2;
+  uint8_t* active = reinterpret_cast<uint8_t*>(L[1] + W2);    // [2W]
+
+  const uint32_t u = a.utt_first + blockIdx.x, tid = threadIdx.x;
+  const uint64_t f0 = a.frame_off[u], T = a.frame_off[u + 1] - f0;
+  const double* dense = a.scores + (f0 - a.frame_base) * a.ld;
+  // per-utterance global workspaces
+  uint32_t* we_slot[2]; float* we_score[2]; uint32_t* we_bp[2];
+  for (int i = 0; i < 2; i++) {
+    const uint64_t o = ((uint64_t)blockIdx.x * 2 + i) * W2;
+    we_slot[i] = a.we_slot + o; we_score[i] = a.we_score + o; we_bp[i] = a.we_bp + o;
+  }
+  uint4* book = a.book + a.book_off[u];  // (word, score bits, backpointer, time)
+  const uint64_t book_cap = a.book_off[u + 1] - a.book_off[u];
+  const float exit_pen[2] = {a.tdp[0][3], a.tdp[1][3]};
+
+  auto map_copy = [&](uint32_t w) { return w == sil ? w : (w >= W ? w - W : w); };
+  auto sil_copy = [&](uint32_t w) { return w == sil ? w : w + W; };
+  auto ac_word = [&](uint32_t w) { return w < W ? w : sil; };
+  auto is_sil = [&](uint32_t w) { return (w == sil || w >= W) ? 1 : 0; };
+
+  for (uint32_t i = tid; i < P2; i += kBgThreads) { st_score[i] = __builtin_inff(); st_bp[i] = 0; }
+  for (uint32_t i = tid; i < W2; i += kBgThreads) active[i] = 0;
+  // initialize (:211-216, :397-418 at t = 0): book[0] = sentinel, book[1] = (silence, 0, self, 0); one word end
+  uint32_t n_book = 2, n_we = 1, n_L = 0;
+  int cur = 0, lcur = 0;  // we_*[cur] = current word ends, L[lcur] = current active list
+  if (tid == 0) {
+    book[0] = make_uint4(0xFFFFFFFFu, __float_as_uint(kFltMax), 0u, 0u);
+    book[1] = make_uint4(sil, __float_as_uint(0.0f), 1u, 0u);
+    we_slot[0][0] = sil; we_score[0][0] = 0.0f; we_bp[0][0] = 1u;
+  }
+  __syncthreads();
+  bool overflow = false;
+
+  for (uint64_t t = 1; t <= T; t++) {
+    // ---- 1 bigramRecombination + LM beam ------------------------------------------------------------------------
+    for (uint32_t i = W + tid; i < W2; i += kBgThreads) en_score[i] = __builtin_inff();
+    if (tid == 0) en_score[sil] = __builtin_inff();
+    float my_score[KW];  // words per thread: W <= KW * kBgThreads
+    uint32_t my_bp[KW];
+#pragma unroll
+    for (int k = 0; k < KW; k++) { my_score[k] = kFltMax; my_bp[k] = 0xFFFFFFFFu; }
+    for (uint32_t e0 = 0; e0 < n_we; e0 += kBgStage) {
+      const uint32_t ne = (n_we - e0 < (uint32_t)kBgStage) ? n_we - e0 : kBgStage;
+      __syncthreads();
+      if (tid < ne) {
+        const uint32_t raw = we_slot[cur][e0 + tid], sl = raw & kSlotMask;
+        stage[3 * tid] = map_copy(sl);
+        stage[3 * tid + 1] = __float_as_uint(we_score[cur][e0 + tid]);
+        stage[3 * tid + 2] = we_bp[cur][e0 + tid];
+        // transition into the silence copy of the word that ended (no LM cost); where the merge left the same word end
+        // twice in the list, addEntryStateHypothesis (:257-268) keeps the LATER start hypothesis
+        if (sl < W && !(raw & kShadowed)) {
+          const uint32_t c = sil_copy(sl);
+          en_score[c] = we_score[cur][e0 + tid];
+          en_bp[c] = we_bp[cur][e0 + tid];
+        }
+      }
+      __syncthreads();
+      // eight word ends at a time: their LM rows are loaded first (independent loads in flight together), then
+      // compared in list order
+      for (uint32_t e = 0; e < ne; e += 8) {
+        float v[8][KW];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const uint32_t ej = (e + j < ne) ? e + j : e;
+          const float* row = a.lmT + (uint64_t)stage[3 * ej] * W;
+#pragma unroll
+          for (int k = 0; k < KW; k++) {
+            const uint32_t w = tid + k * kBgThreads;
+            v[j][k] = row[w < W ? w : 0];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          if (e + j < ne) {  // workgroup-uniform
+            const float sc = __uint_as_float(stage[3 * (e + j) + 1]);
+            const uint32_t bp = stage[3 * (e + j) + 2];
+#pragma unroll
+            for (int k = 0; k < KW; k++) {
+              const float ns = sc + v[j][k];
+              if (ns < my_score[k]) { my_score[k] = ns; my_bp[k] = bp; }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    float lmin = kFltMax;
+#pragma unroll
+    for (int k = 0; k < KW; k++) {
+      const uint32_t w = tid + k * kBgThreads;
+      if (w < W && w != sil) {
+        en_score[w] = my_score[k];
+        en_bp[w] = my_bp[k];
+        lmin = fminf(lmin, my_score[k]);
+      }
+    }
+    __syncthreads();
+    for (uint32_t i = W + tid; i < W2; i += kBgThreads) lmin = fminf(lmin, en_score[i]);
+    if (tid == 0) lmin = fminf(lmin, en_score[sil]);
+    const float best_start = wg_min(lmin, red_tmp);
+    float lm_thr = a.lm_pruning;
+    if (lm_thr < kFltMax) lm_thr += best_start;
+
+    // ---- 2 activation in start-list order: words ascending, then silence copies in word-end order ----------------
+    {
+      // (a) words: thread k owns the contiguous words [k*cw, (k+1)*cw)
+      const uint32_t cw = (W + kBgThreads - 1) / kBgThreads;
+      const uint32_t w_lo = tid * cw, w_hi = (w_lo + cw < W) ? w_lo + cw : W;
+      uint32_t cnt = 0;
+      for (uint32_t w = w_lo; w < w_hi; w++) {
+        if (w == sil) continue;  // en_score[sil] is the silence "copy" entered after silence: handled in (b)
+        const bool ins = en_score[w] < lm_thr;
+        if (!ins) en_score[w] = __builtin_inff();
+        else if (!active[w]) cnt++;
+      }
+      uint32_t total;
+      uint32_t pos = n_L + wg_excl_scan(cnt, scan_tmp, &total);
+      for (uint32_t w = w_lo; w < w_hi; w++)
+        if (w != sil && en_score[w] < __builtin_inff() && !active[w]) { L[lcur][pos++] = (uint16_t)w; active[w] = 1; }
+      n_L += total;
+      // (b) silence copies, in the order of the word ends that start them
+      const uint32_t ce = (n_we + kBgThreads - 1) / kBgThreads;
+      const uint32_t e_lo = tid * ce, e_hi = (e_lo + ce < n_we) ? e_lo + ce : n_we;
+      cnt = 0;
+      for (uint32_t e = e_lo; e < e_hi; e++) {
+        const uint32_t raw = we_slot[cur][e], sl = raw & kSlotMask;
+        if (sl < W && !(raw & kRepeat)) {  // (a repeated word end activates nothing new: its first occurrence did)
+          const uint32_t c = sil_copy(sl);
+          const bool ins = en_score[c] < lm_thr;
+          if (!ins) en_score[c] = __builtin_inff();
+          else if (!active[c]) cnt++;
+        }
+      }
+      pos = n_L + wg_excl_scan(cnt, scan_tmp, &total);
+      for (uint32_t e = e_lo; e < e_hi; e++) {
+        const uint32_t raw = we_slot[cur][e], sl = raw & kSlotMask;
+        if (sl < W && !(raw & kRepeat)) {
+          const uint32_t c = sil_copy(sl);
+          if (en_score[c] < __builtin_inff() && !active[c]) { L[lcur][pos++] = (uint16_t)c; active[c] = 1; }
+        }
+      }
+      n_L += total;
+      __syncthreads();
+    }
+
+    // ---- 3 expandHypotheses + addAcousticScores; thread k owns the contiguous list entries [k*cl, (k+1)*cl) ---------
+    const uint32_t cl = (n_L + kBgThreads - 1) / kBgThreads;
+    const uint32_t i_lo = tid * cl, i_hi = (i_lo + cl < n_L) ? i_lo + cl : n_L;
+    const double* row = dense + (t - 1) * a.ld;
+    float lbest = kFltMax;
+    for (uint32_t i = i_lo; i < i_hi; i++) {
+      const uint32_t sl = L[lcur][i];
+      const uint32_t base = a.slot_off[sl], n = a.slot_off[sl + 1] - base, mixbase = a.slot_mix[sl];
+      const int s_ = is_sil(sl);
+      const float t0 = a.tdp[s_][0], t1 = a.tdp[s_][1], t2 = a.tdp[s_][2];
+      const float ent = en_score[sl];
+      const uint32_t ent_bp = en_bp[sl];
+      for (uint32_t s = n; s >= 1; s--) {  // in place: the new state s needs the old states s-2, s-1, s only
+        float best = __builtin_inff();
+        uint32_t bbp = 0;
+        // candidates in the order the reference creates them: ascending predecessor state; >= lets the later one win
+        if (s <= 2 && ent < __builtin_inff()) {  // from the virtual entry state 0: free to state 1, skip penalty to state 2
+          const float c = (s == 1) ? ent : ent + t2;
+          best = c; bbp = ent_bp;
+        }
+        if (s >= 3) {
+          const float o = st_score[base + s - 3];
+          if (o < __builtin_inff()) { const float c = o + t2; if (!(best < c)) { best = c; bbp = st_bp[base + s - 3]; } }
+        }
+        if (s >= 2) {
+          const float o = st_score[base + s - 2];
+          if (o < __builtin_inff()) { const float c = o + t1; if (!(best < c)) { best = c; bbp = st_bp[base + s - 2]; } }
+        }
+        {
+          const float o = st_score[base + s - 1];
+          if (o < __builtin_inff()) { const float c = o + t0; if (!(best < c)) { best = c; bbp = st_bp[base + s - 1]; } }
+        }
+        if (best < __builtin_inff()) {
+          best += (float)row[a.mixtures[mixbase + s - 1]];
+          lbest = fminf(lbest, best);
+        }
+        st_score[base + s - 1] = best;
+        st_bp[base + s - 1] = bbp;
+      }
+    }
+    const float best_score = wg_min(lbest, red_tmp);
+    float ac_thr = a.ac_pruning;
+    if (ac_thr < kFltMax) ac_thr += best_score;
+
+    // ---- 4 pruneStatesAndFindWordEnds: ordered compaction of the active list and of the word ends ------------------
+    uint32_t n_alive = 0, n_ends = 0;
+    for (uint32_t i = i_lo; i < i_hi; i++) {
+      const uint32_t sl = L[lcur][i];
+      const uint32_t base = a.slot_off[sl], n = a.slot_off[sl + 1] - base;
+      const float xp = exit_pen[is_sil(sl)];
+      bool alive = false;
+      for (uint32_t s = 1; s <= n; s++) {
+        const float sc = st_score[base + s - 1];
+        if (sc < __builtin_inff()) {
+          const float tv = sc + xp;
+          if (tv < ac_thr) { alive = true; if (s == n) n_ends++; }
+          else st_score[base + s - 1] = __builtin_inff();
+        }
+      }
+      if (alive) n_alive++; else active[sl] = 0;
+    }
+    uint32_t tot_alive, tot_ends;
+    uint32_t pa = wg_excl_scan(n_alive, scan_tmp, &tot_alive);
+    uint32_t pe = wg_excl_scan(n_ends, scan_tmp, &tot_ends);
+    const int nxt = cur ^ 1;
+    for (uint32_t i = i_lo; i < i_hi; i++) {
+      const uint32_t sl = L[lcur][i];
+      if (!active[sl]) continue;
+      L[lcur ^ 1][pa++] = (uint16_t)sl;
+      const uint32_t base = a.slot_off[sl], n = a.slot_off[sl + 1] - base;
+      const float sc = st_score[base + n - 1];
+      if (sc < __builtin_inff()) {  // the final state survived: a word end, carrying the exit-penalised score
+        we_slot[nxt][pe] = sl;
+        we_score[nxt][pe] = sc + exit_pen[is_sil(sl)];
+        we_bp[nxt][pe] = st_bp[base + n - 1];
+        pe++;
+      }
+    }
+    lcur ^= 1;
+    n_L = tot_alive;
+    __syncthreads();  // the word-end list in global memory is complete (same workgroup: visible after the barrier)
+
+    // ---- 5 mergeSilenceToBigramNodes.  first[h] / last[h] = first / last index of a word end with history h; the
+    // reference writes the better of the (at most two) into the FIRST index and then keeps list[0 .. #histories) --------
+    uint32_t* first = reinterpret_cast<uint32_t*>(en_score);  // [W] (entries are consumed; rebuilt next frame)
+    uint32_t* last = en_bp;                                   // [W]
+    for (uint32_t h = tid; h < W; h += kBgThreads) { first[h] = 0xFFFFFFFFu; last[h] = 0u; }
+    __syncthreads();
+    for (uint32_t e = tid; e < tot_ends; e += kBgThreads) {
+      const uint32_t h = map_copy(we_slot[nxt][e]);
+      atomicMin(&first[h], e);
+      atomicMax(&last[h], e);
+    }
+    __syncthreads();
+    uint32_t nh = 0;
+    for (uint32_t e = tid; e < tot_ends; e += kBgThreads)
+      if (first[map_copy(we_slot[nxt][e])] == e) nh++;
+    uint32_t n_hist;
+    (void)wg_excl_scan(nh, scan_tmp, &n_hist);
+    // ---- 6 addBookKeepingEntries for the kept word ends e = 0 .. n_hist-1, in list order -----------------------------
+    if ((uint64_t)n_book + n_hist > book_cap) { overflow = true; break; }  // workgroup-uniform
+    for (uint32_t e = tid; e < n_hist; e += kBgThreads) {
+      const uint32_t h = map_copy(we_slot[nxt][e]);
+      uint32_t src = e, mark = 0;
+      if (first[h] == e) {
+        const uint32_t j = last[h];
+        if (j != e && we_score[nxt][j] <= we_score[nxt][e]) {  // <=: the later one wins a tie
+          src = j;
+          if (j < n_hist) mark = kShadowed;  // ... and stays in the list at its own index too
+        }
+      } else {
+        const uint32_t i = first[h];  // (i < e < n_hist) did index i take over this entry?
+        if (we_score[nxt][e] <= we_score[nxt][i]) mark = kRepeat;
+      }
+      const uint32_t sl = we_slot[nxt][src];
+      const float sc = we_score[nxt][src];
+      uint32_t bp = we_bp[nxt][src];
+      if (sl == sil) {  // avoid chains of silence (:410-415); entries store acoustic words, copies count as silence
+        const uint4 prev = book[bp];
+        if (prev.x == sil) bp = prev.z;
+      }
+      const uint32_t nb = n_book + e;
+      book[nb] = make_uint4(ac_word(sl), __float_as_uint(sc), bp, (uint32_t)t);
+      // the merged list for the next frame goes to the other buffer (reads above are from `nxt`, writes to `cur`)
+      we_slot[cur][e] = sl | mark; we_score[cur][e] = sc; we_bp[cur][e] = nb;
+    }
+    n_book += n_hist;
+    n_we = n_hist;
+    __syncthreads();
+    // we_*[cur] now holds the new word ends: `cur` stays
+  }
+
+  // ---- traceback (:420-436): first minimum in list order --------------------------------------------------------
+  if (tid == 0) {
+    uint32_t n_out = 0;
+    if (overflow) {
+      a.out_flags[u] = 1;
+    } else {
+      a.out_flags[u] = 0;
+      if (n_we > 0) {
+        uint32_t bi = 0;
+        float bs = we_score[cur][0];
+        for (uint32_t i = 1; i < n_we; i++) { const float s = we_score[cur][i]; if (s < bs) { bs = s; bi = i; } }
+        const uint32_t bp0 = we_bp[cur][bi];
+        uint32_t len = 0;
+        for (uint32_t b = bp0; book[b].w > 0; b = book[b].z) len++;
+        n_out = len;
+        const uint64_t o = f0 + u;  // T_u + 1 output slots per utterance
+        for (uint32_t b = bp0; book[b].w > 0; b = book[b].z) {
+          len--;
+          const uint4 e = book[b];
+          a.out_word[o + len] = e.x; a.out_score[o + len] = __uint_as_float(e.y); a.out_time[o + len] = e.w;
+        }
+      }
+    }
+    a.out_count[u] = n_out;
+  }
+}
+
+size_t bigram_lds_bytes(uint32_t n_words, uint32_t n_positions) {
+  const size_t W2 = 2 * (size_t)n_words;
+  return (size_t)n_positions * 8 + W2 * 8 + (3 * kBgStage + kBgWaves + 1 + kBgWaves) * 4 + W2 * 2 * 2 + W2 + 64;
+}
+uint32_t bigram_max_words() { return 8 * kBgThreads; }
+
+hipError_t launch_bigram(const BigramArgs& a, hipStream_t stream) {
+  if (a.n_utts == 0) return hipSuccess;
+  const size_t smem = (bigram_lds_bytes(a.n_words, a.n_positions) + 15) & ~(size_t)15;
+  auto go = [&](auto kernel) {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(a.n_utts), dim3(kBgThreads), smem, stream, a);
+    return hipGetLastError();
+  };
+  const uint32_t kw = (a.n_words + kBgThreads - 1) / kBgThreads;
+  if (kw <= 1) return go(bigram_kernel<1>);
+  if (kw <= 2) return go(bigram_kernel<2>);
+  if (kw <= 4) return go(bigram_kernel<4>);
+  return go(bigram_kernel<8>);
+}
+
+}  // namespace srgpu
