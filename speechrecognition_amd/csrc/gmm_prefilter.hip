@@ -418,9 +418,6 @@ int gmm_prefilter_frames_per_tile(int fp16) { return kPWaves * (fp16 ? SR_P16_NB
 #ifndef SR_R_THREADS
 #define SR_R_THREADS 768
 #endif
-#ifndef SR_R_EXP
-#define SR_R_EXP 0
-#endif
 #ifndef SR_R_BATCH
 #define SR_R_BATCH 4
 #endif
@@ -460,11 +457,7 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
     double x[DT ? DT : 1];
     if (DT) {
 #pragma unroll
-#if SR_R_EXP == 3  /* timing experiment: no feature loads */
-      for (int k = 0; k < DT; k++) x[k] = (double)(f + k) * 1e-6;
-#else
       for (int k = 0; k < DT; k++) x[k] = (double)a.featsT[(uint64_t)k * a.n_frames_ld + f];
-#endif
     }
     auto X = [&](uint32_t k) -> double { return DT ? x[DT ? k : 0] : (double)a.featsT[(uint64_t)k * a.n_frames_ld + f]; };
     // score of the density whose plane column starts at LDS address `col0`, in density_score_sse's operation order
@@ -489,25 +482,17 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
 #pragma unroll
           for (int i = 0; i < kRBatch; i++) {
             const int k = (b + 1) * kRBatch + i;
-#if SR_R_EXP == 1  /* timing experiment: arithmetic only */
-            if (k <= DT) { pm[cur ^ 1][i] = pm[cur][i] + 1.0; pv[cur ^ 1][i] = pv[cur][i]; }
-#else
             if (k <= DT) { pm[cur ^ 1][i] = col[(2 * k) * NS]; pv[cur ^ 1][i] = col[(2 * k + 1) * NS]; }
-#endif
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int i = 0; i < kRBatch; i++) {
             const int k = b * kRBatch + i;
             if (k < (int)(DT - (DT & 1))) {
-#if SR_R_EXP == 2  /* timing experiment: reads only */
-              if (k & 1) l1 = l1 + pm[cur][i]; else l0 = l0 + pv[cur][i];
-#else
               double u = x[DT ? k : 0] - pm[cur][i];
               u = u * u;
               u = u * pv[cur][i];
               if (k & 1) l1 = l1 + u; else l0 = l0 + u;
-#endif
             } else if (k == DT - 1) {  // odd dimension count: scalar tail (Mixtures.cpp:680-683)
               dist = l0 + l1;
               const double t = x[DT ? k : 0] - pm[cur][i];

@@ -263,3 +263,29 @@ def test_gpu_bigram_ties_and_merge_quirk(tmp_path, oracle_lib):
         corpus.close()
         bg.close()
     o.close()
+
+
+@pytest.mark.gpu
+def test_gpu_bigram_limits_and_errors(tmp_path, oracle_lib):
+    """Book capacity (max_word_ends) -> SR_ELIMIT instead of a silent truncation; argument checks."""
+    from speechrecognition_amd import capi
+
+    lex, spec, mp, word_off, mixtures, lm, tdp, feats = _setup(tmp_path, 21, 30, 3)
+    with capi.Model.from_mixset(mp, 12) as m:
+        with pytest.raises(capi.SrError):
+            m.bigram(word_off, mixtures, lex.n_words, lm, tdp)            # silence word out of range
+        bad = mixtures.copy()
+        bad[3] = 60000
+        with pytest.raises(capi.SrError):
+            m.bigram(word_off, bad, lex.silence_idx, lm, tdp)             # mixture index out of range
+        bg = m.bigram(word_off, mixtures, lex.silence_idx, lm, tdp)
+        corpus = m.upload(feats, np.array([0, len(feats)], np.uint64))
+        w, s, t, off = corpus.recognize_bigram(bg, 200.0, capi.FLT_MAX)  # default capacity: cannot overflow
+        assert len(w) > 0
+        with pytest.raises(capi.SrError) as ei:
+            corpus.recognize_bigram(bg, 200.0, capi.FLT_MAX, max_word_ends=1)
+        assert ei.value.code == -4  # SR_ELIMIT (include/srgpu.h)
+        w2, s2, t2, off2 = corpus.recognize_bigram(bg, 200.0, capi.FLT_MAX)  # the handle survives the error
+        assert np.array_equal(w, w2) and np.array_equal(s.view(np.uint32), s2.view(np.uint32))
+        corpus.close()
+        bg.close()
