@@ -151,6 +151,7 @@ struct BigramArgs {
   const uint32_t* slot_mix;     // [2W] offset of the slot's acoustic word in `mixtures`
   const uint16_t* mixtures;     // emission state per lexicon position
   const float* lmT;             // [W x W] transposed: lmT[h*W + w] = -log p(w | h)
+  const float *lm_rowmin, *lm_rowmax;  // [W] min / max over w != silence of lmT[h][w]
   float tdp[2][4];              // [isSilence][loop, forward, skip, exit]
   float ac_pruning, lm_pruning; // >= FLT_MAX: off
   uint32_t *we_slot, *we_bp; float* we_score;  // workspace [n_utts][2][2W]

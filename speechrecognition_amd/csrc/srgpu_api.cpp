@@ -151,7 +151,7 @@ struct sr_bigram {
   float tdp[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   DevBuf<uint32_t> slot_off, slot_mix;
   DevBuf<uint16_t> mixtures;
-  DevBuf<float> lmT;
+  DevBuf<float> lmT, lm_rowmin, lm_rowmax;
   // workspace
   DevBuf<uint32_t> we_slot, we_bp, out_word, out_time, out_count, out_flags;
   DevBuf<float> we_score, out_score;
@@ -932,13 +932,23 @@ int sr_bigram_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, co
   std::vector<float> lmT((size_t)W * W);
   for (uint32_t w = 0; w < W; w++)
     for (uint32_t h = 0; h < W; h++) lmT[(size_t)h * W + w] = lm[(size_t)w * W + h];
+  std::vector<float> rowmin(W, std::numeric_limits<float>::infinity()), rowmax(W, -std::numeric_limits<float>::infinity());
+  for (uint32_t h = 0; h < W; h++)
+    for (uint32_t w = 0; w < W; w++) {
+      if (w == silence_word) continue;  // no transition into silence through the LM (LinearSearch.cc:231)
+      const float v = lmT[(size_t)h * W + w];
+      // NaN entries: the bounds become NaN and the skip test fails safe (nothing is skipped against a NaN bound)
+      rowmin[h] = (v < rowmin[h] || v != v) ? v : rowmin[h];
+      rowmax[h] = (v > rowmax[h] || v != v) ? v : rowmax[h];
+    }
   sr_bigram* b = new sr_bigram();
   b->model = m; b->n_words = W; b->silence = silence_word; b->n_positions = P2;
   memcpy(b->tdp, tdp, sizeof(b->tdp));
   hipError_t e;
   if ((e = b->slot_off.upload(slot_off.data(), slot_off.size())) != hipSuccess ||
       (e = b->slot_mix.upload(slot_mix.data(), slot_mix.size())) != hipSuccess ||
-      (e = b->mixtures.upload(mixtures, word_off[W])) != hipSuccess || (e = b->lmT.upload(lmT.data(), lmT.size())) != hipSuccess) {
+      (e = b->mixtures.upload(mixtures, word_off[W])) != hipSuccess || (e = b->lmT.upload(lmT.data(), lmT.size())) != hipSuccess ||
+      (e = b->lm_rowmin.upload(rowmin.data(), W)) != hipSuccess || (e = b->lm_rowmax.upload(rowmax.data(), W)) != hipSuccess) {
     sr_bigram_destroy(b);
     return fail(SR_EHIP, "bigram upload: %s", hipGetErrorString(e));
   }
@@ -949,7 +959,7 @@ int sr_bigram_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, co
 int sr_bigram_destroy(sr_bigram* b) {
   if (!b) return SR_OK;
   if (b->model) { (void)hipSetDevice(b->model->device); (void)hipDeviceSynchronize(); }
-  b->slot_off.release(); b->slot_mix.release(); b->mixtures.release(); b->lmT.release();
+  b->slot_off.release(); b->slot_mix.release(); b->mixtures.release(); b->lmT.release(); b->lm_rowmin.release(); b->lm_rowmax.release();
   b->we_slot.release(); b->we_bp.release(); b->we_score.release(); b->book.release(); b->book_off.release();
   b->out_word.release(); b->out_time.release(); b->out_score.release(); b->out_count.release(); b->out_flags.release();
   delete b;
@@ -987,7 +997,7 @@ int sr_recognize_bigram_corpus(sr_model* m, sr_corpus* c, sr_bigram* b, const sr
   BigramArgs ba{};
   ba.ld = m->ld; ba.frame_off = c->d_frame_off.p;
   ba.n_words = W; ba.silence = b->silence; ba.n_positions = b->n_positions;
-  ba.slot_off = b->slot_off.p; ba.slot_mix = b->slot_mix.p; ba.mixtures = b->mixtures.p; ba.lmT = b->lmT.p;
+  ba.slot_off = b->slot_off.p; ba.slot_mix = b->slot_mix.p; ba.mixtures = b->mixtures.p; ba.lmT = b->lmT.p; ba.lm_rowmin = b->lm_rowmin.p; ba.lm_rowmax = b->lm_rowmax.p;
   memcpy(ba.tdp, b->tdp, sizeof(ba.tdp));
   ba.ac_pruning = p->acoustic_pruning; ba.lm_pruning = p->lm_pruning;
   ba.we_slot = b->we_slot.p; ba.we_bp = b->we_bp.p; ba.we_score = b->we_score.p;

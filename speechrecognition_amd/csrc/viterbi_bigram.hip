@@ -130,20 +130,52 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
     uint32_t my_bp[KW];
 #pragma unroll
     for (int k = 0; k < KW; k++) { my_score[k] = kFltMax; my_bp[k] = 0xFFFFFFFFu; }
+    // Word ends that cannot win any word are skipped -- exactly: after the row of word end e every start score is
+    // <= score_e + rowmax[h_e], so U = min_e (score_e + rowmax[h_e]) bounds all final start scores; a word end with
+    // score_e + rowmin[h_e] > U can never produce "newScore < start[w]" (float addition is monotone, so the bounds hold
+    // for the rounded sums).  With a beam of 200 over LM scores spanning ~10 this drops most of the E x W work.
+    float lu = kFltMax;
+    for (uint32_t e = tid; e < n_we; e += kBgThreads)
+      lu = fminf(lu, we_score[cur][e] + a.lm_rowmax[map_copy(we_slot[cur][e] & kSlotMask)]);
+    const float U = wg_min(lu, red_tmp);
     for (uint32_t e0 = 0; e0 < n_we; e0 += kBgStage) {
-      const uint32_t ne = (n_we - e0 < (uint32_t)kBgStage) ? n_we - e0 : kBgStage;
+      const uint32_t ne_in = (n_we - e0 < (uint32_t)kBgStage) ? n_we - e0 : kBgStage;
       __syncthreads();
-      if (tid < ne) {
+      // stage the surviving word ends of this chunk, in list order (ballot prefix within the chunk's four waves)
+      bool keep = false;
+      uint32_t h = 0;
+      float sc_e = 0.0f;
+      uint32_t bp_e = 0;
+      if (tid < ne_in) {
         const uint32_t raw = we_slot[cur][e0 + tid], sl = raw & kSlotMask;
-        stage[3 * tid] = map_copy(sl);
-        stage[3 * tid + 1] = __float_as_uint(we_score[cur][e0 + tid]);
-        stage[3 * tid + 2] = we_bp[cur][e0 + tid];
+        h = map_copy(sl);
+        sc_e = we_score[cur][e0 + tid];
+        bp_e = we_bp[cur][e0 + tid];
+        keep = !(sc_e + a.lm_rowmin[h] > U);
         // transition into the silence copy of the word that ended (no LM cost); where the merge left the same word end
         // twice in the list, addEntryStateHypothesis (:257-268) keeps the LATER start hypothesis
         if (sl < W && !(raw & kShadowed)) {
           const uint32_t c = sil_copy(sl);
-          en_score[c] = we_score[cur][e0 + tid];
-          en_bp[c] = we_bp[cur][e0 + tid];
+          en_score[c] = sc_e;
+          en_bp[c] = bp_e;
+        }
+      }
+      const uint64_t bal = __ballot(keep);
+      if (tid < kBgStage && (tid & 63) == 0) scan_tmp[tid >> 6] = (uint32_t)__popcll(bal);
+      __syncthreads();
+      uint32_t ne = 0;
+      {
+        uint32_t before = 0;
+        for (int wv = 0; wv < kBgStage / 64; wv++) {
+          const uint32_t c = scan_tmp[wv];
+          if (wv < (int)(tid >> 6)) before += c;
+          ne += c;
+        }
+        if (keep) {
+          const uint32_t pos = before + (uint32_t)__popcll(bal & ((1ull << (tid & 63)) - 1ull));
+          stage[3 * pos] = h;
+          stage[3 * pos + 1] = __float_as_uint(sc_e);
+          stage[3 * pos + 2] = bp_e;
         }
       }
       __syncthreads();
