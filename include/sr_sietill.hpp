@@ -507,4 +507,62 @@ class Trainer {
   TdpModel tdp_;
 };
 
+// ---- Teaching::LinearSearch (rwth-asr-0.5/src/Teaching/LinearSearch.hh:9-62, SearchInterface.hh:20-30) -------------
+// Bigram-LM beam search over a linear lexicon, one device pass per corpus.  The toolkit wires lexicon, language model
+// and transition model through Speech::ModelCombination (LinearSearch.cc:462-475); here they are plain arrays:
+//   linear_lexicon[w] = mixture (emission state) sequence of word w (LinearSearch::buildLinearLexicon :477-483),
+//   lm[w * W + h]     = getLanguageModelScore(w, h) = -log p(w | h) (SearchInterface.cc:77-81),
+//   tdp[isSilence][loop, forward, skip, exit] (SearchSpace::setTransitionScores :169-180).
+// Parameters keep the reference's names: "acoustic-pruning", "lm-pruning" (:438-446), infinity = no beam.
+class LinearSearch {
+ public:
+  struct TracebackItem {  // SearchInterface::TracebackItem
+    uint32_t word;
+    float score;
+    uint32_t time;
+  };
+  typedef std::vector<TracebackItem> Traceback;
+
+  LinearSearch(MixtureModel& scorer, std::vector<std::vector<uint16_t> > const& linear_lexicon, uint32_t silence,
+               std::vector<float> const& lm, const float tdp[2][4], float acoustic_pruning = std::numeric_limits<float>::max(),
+               float lm_pruning = std::numeric_limits<float>::max())
+      : scorer_(scorer), acoustic_pruning_(acoustic_pruning), lm_pruning_(lm_pruning) {
+    std::vector<uint32_t> word_off(1, 0);
+    std::vector<uint16_t> mixtures;
+    for (size_t w = 0; w < linear_lexicon.size(); w++) {
+      mixtures.insert(mixtures.end(), linear_lexicon[w].begin(), linear_lexicon[w].end());
+      word_off.push_back((uint32_t)mixtures.size());
+    }
+    if (lm.size() != linear_lexicon.size() * linear_lexicon.size()) throw std::runtime_error("LinearSearch: lm must be W x W");
+    check(sr_bigram_create(scorer.handle(), (uint32_t)linear_lexicon.size(), word_off.data(), mixtures.data(), silence, lm.data(),
+                           &tdp[0][0], &net_));
+  }
+  ~LinearSearch() { sr_bigram_destroy(net_); }
+  LinearSearch(LinearSearch const&) = delete;
+  LinearSearch& operator=(LinearSearch const&) = delete;
+
+  // initialize() + processFrame(1..T) + getResult() (LinearSearch.cc:489-520) for every segment of the corpus
+  void recognize(Corpus const& corpus, std::vector<Traceback>& results) {
+    const size_t n = corpus.get_corpus_size();
+    const uint64_t F = corpus.get_total_frame_count();
+    std::vector<uint32_t> words(F + n + 1), times(F + n + 1);
+    std::vector<float> scores(F + n + 1);
+    std::vector<uint64_t> off(n + 1);
+    sr_corpus* c = nullptr;
+    check(sr_corpus_upload(scorer_.handle(), corpus.features(), corpus.frame_offsets(), (uint32_t)n, &c));
+    const sr_bigram_params p = {acoustic_pruning_, lm_pruning_, scorer_.gmm_kernel, 0};
+    const int rc = sr_recognize_bigram_corpus(scorer_.handle(), c, net_, &p, words.data(), scores.data(), times.data(), off.data());
+    sr_corpus_destroy(c);
+    check(rc);
+    results.assign(n, Traceback());
+    for (size_t s = 0; s < n; s++)
+      for (uint64_t i = off[s]; i < off[s + 1]; i++) results[s].push_back(TracebackItem{words[i], scores[i], times[i]});
+  }
+
+ private:
+  MixtureModel& scorer_;
+  float acoustic_pruning_, lm_pruning_;
+  sr_bigram* net_ = nullptr;
+};
+
 }  // namespace sr

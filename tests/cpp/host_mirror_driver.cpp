@@ -136,6 +136,24 @@ int main(int argc, char** argv) {
       printf("\nrealign_states");
       for (auto const& it : corpus_ali) printf(" %u", it.state);
       printf("\namscore %.17g\n", trainer.calc_am_score(corpus, corpus_ali));
+      // bigram search mirror (Teaching::LinearSearch): the digit-style lexicon as a linear lexicon, a fixed dense LM
+      {
+        const uint32_t W = (uint32_t)lex.num_words();
+        std::vector<std::vector<uint16_t>> linear(W);
+        for (uint32_t w = 0; w < W; w++) linear[w] = lex.get_automaton_for_word(w).states;
+        std::vector<float> lm((size_t)W * W);
+        for (uint32_t w = 0; w < W; w++)
+          for (uint32_t h = 0; h < W; h++) lm[(size_t)w * W + h] = 2.0f + 0.5f * (float)((7 * w + 3 * h) % 11);
+        const float btdp[2][4] = {{3.0f, 0.0f, 30.0f, 5.0f}, {1.0f, 0.0f, 40.0f, 2.0f}};
+        sr::LinearSearch search(mm, linear, sil, lm, btdp, 150.0f, 20.0f);
+        std::vector<sr::LinearSearch::Traceback> res;
+        search.recognize(corpus, res);
+        for (auto const& tb : res) {
+          printf("bigram");
+          for (auto const& it : tb) printf(" %u:%.9g:%u", it.word, it.score, it.time);
+          printf("\n");
+        }
+      }
     } catch (std::exception const& e) {
       printf("error %s\n", e.what());
       return 2;

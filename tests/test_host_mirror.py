@@ -121,4 +121,19 @@ def test_recognizer_and_aligner_mirror_on_gpu(driver, tmp_path, oracle_lib, kern
         assert am == total / k
     else:
         assert abs(am - total / k) <= 1e-9 * abs(am)
+    # sr::LinearSearch mirror against the bigram restatement (parity unpinned, tests/test_bigram.py)
+    W = lex.n_words
+    lm = np.array([[2.0 + 0.5 * ((7 * w + 3 * h) % 11) for h in range(W)] for w in range(W)], np.float32)
+    btdp = np.array([[3.0, 0.0, 30.0, 5.0], [1.0, 0.0, 40.0, 2.0]], np.float32)
+    blines = [l.split()[1:] for l in out if l.startswith("bigram")]
+    assert len(blines) == len(utts)
+    for f, items in zip(utts, blines):
+        w, s, t = oracle_lib.bigram_decode(o.score_matrix(f), word_off, automaton, lex.silence_idx, lm, btdp, 150.0, 20.0)
+        got = [it.split(":") for it in items]
+        assert [int(g[0]) for g in got] == list(w) and [int(g[2]) for g in got] == list(t)
+        gs = np.array([float(g[1]) for g in got], np.float32)
+        if kernel == 1:
+            assert np.array_equal(gs, s)
+        else:
+            np.testing.assert_allclose(gs, s, rtol=1e-6)
     o.close()
