@@ -11,7 +11,8 @@
 //                         in soft mode (entries below 1e-8 are dropped like :334-336);
 //   2. a STABLE radix sort of the pairs by mean index (and again by variance index: tied variances are summed
 //      across the densities sharing them, in frame order);
-//   3. em_sum_kernel      one wave per accumulator row walks its pairs in order, lanes = feature dimensions:
+//   3. em_bounds_kernel   first pair of every accumulator row (binary search per row), then
+//      em_sum_kernel      one thread per (row, dimension) walks the row's pairs in order:
 //                         mean_acc += w*x, var_acc += (w*x)*x (starting at 1e-4, :243), weight += w.
 // Parallelism is across rows (10^5 of them), never inside a row.  Soft mode uses the device exp, so its
 // weights differ from glibc's by an ulp or two: tolerance 1e-12 there, bit-exact otherwise.
@@ -91,34 +92,50 @@ __global__ __launch_bounds__(kAssignThreads) void em_assign_kernel(EmArgs a) {
   }
 }
 
-// one wave per accumulator row; SQUARE: variance statistics
-template <bool SQUARE>
-__global__ __launch_bounds__(64) void em_sum_kernel(EmArgs a, const uint32_t* sorted_keys, const uint32_t* sorted_pairs,
-                                                    uint32_t n_rows, double* acc, double* weight) {
-  const uint32_t row = blockIdx.x, lane = threadIdx.x;
-  if (row >= n_rows) return;
-  // [lo, hi) = pairs whose key is `row` (binary search; every lane does the same search)
-  uint64_t lo = 0, hi = a.n_pairs;
+// row_begin[r] = first pair whose key is >= r (r = 0 .. n_rows): one thread per row, a binary search each
+__global__ __launch_bounds__(256) void em_bounds_kernel(const uint32_t* sorted_keys, uint64_t n_pairs, uint32_t n_rows,
+                                                        uint32_t* row_begin) {
+  const uint32_t row = blockIdx.x * 256 + threadIdx.x;
+  if (row > n_rows) return;
+  uint64_t lo = 0, hi = n_pairs;
   while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (sorted_keys[mid] < row) lo = mid + 1; else hi = mid; }
-  uint64_t e = lo, hi2 = a.n_pairs;
-  while (e < hi2) { const uint64_t mid = (e + hi2) >> 1; if (sorted_keys[mid] <= row) e = mid + 1; else hi2 = mid; }
+  row_begin[row] = (uint32_t)lo;
+}
+
+// one thread per (accumulator row, dimension), rows' pairs walked in order; SQUARE: variance statistics
+template <bool SQUARE>
+__global__ __launch_bounds__(256) void em_sum_kernel(EmArgs a, const uint32_t* row_begin, const uint32_t* sorted_pairs,
+                                                     uint32_t n_rows, double* acc, double* weight) {
   const uint32_t D = a.dim;
-  for (uint32_t d0 = 0; d0 < D; d0 += 64) {
-    const uint32_t d = d0 + lane;
-    double sum = SQUARE ? 1e-4 : 0.0;  // reset_accumulators: variances start at minimal_variance_value_ (:167,243)
-    double w = 0.0;
-    for (uint64_t i = lo; i < e; i++) {
-      const uint32_t pair = sorted_pairs[i];
-      const double p = a.pair_w[pair];
-      const float xv = d < D ? a.feats[(uint64_t)a.pair_frame[pair] * D + d] : 0.0f;
-      const double y = (double)xv;
-      if (SQUARE) sum = sum + p * y * y;  // scale_add_square: x + scale * y * y  (:56-64)
-      else sum = sum + p * y;             // scale_add:        x + scale * y      (:46-54)
-      w += p;
+  const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const uint32_t row = (uint32_t)(idx / D), d = (uint32_t)(idx % D);
+  if (row >= n_rows) return;
+  const uint32_t lo = row_begin[row], e = row_begin[row + 1];
+  double sum = SQUARE ? 1e-4 : 0.0;  // reset_accumulators: variances start at minimal_variance_value_ (:167,243)
+  double w = 0.0;
+  // The additions must stay in corpus order (bit-exactness), but the operands of many pairs can be in flight at
+  // once: a row that collects tens of thousands of frames (silence) is then bound by the add chain, not by three
+  // dependent loads per frame.
+  for (uint32_t i = lo; i < e; i += 16) {
+    double pp[16], yy[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint32_t ij = (i + j < e) ? i + j : i;
+      const uint32_t pair = sorted_pairs[ij];
+      pp[j] = a.pair_w[pair];
+      yy[j] = (double)a.feats[(uint64_t)a.pair_frame[pair] * D + d];
     }
-    if (d < D) acc[(uint64_t)row * D + d] = sum;
-    if (d0 == 0 && lane == 0) weight[row] = w;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      if (i + j < e) {
+        if (SQUARE) sum = sum + pp[j] * yy[j] * yy[j];  // scale_add_square: x + scale * y * y  (:56-64)
+        else sum = sum + pp[j] * yy[j];                 // scale_add:        x + scale * y      (:46-54)
+        w += pp[j];
+      }
+    }
   }
+  acc[(uint64_t)row * D + d] = sum;
+  if (d == 0) weight[row] = w;
 }
 
 size_t em_sort_temp_bytes(uint64_t n_pairs) {
@@ -129,7 +146,7 @@ size_t em_sort_temp_bytes(uint64_t n_pairs) {
 }
 
 hipError_t launch_em_accumulate(const EmArgs& a, void* sort_temp, size_t sort_temp_bytes, uint32_t* iota, uint32_t* keys_sorted,
-                                uint32_t* pairs_sorted, double* mean_acc, double* mean_w, double* var_acc, double* var_w,
+                                uint32_t* pairs_sorted, uint32_t* row_begin, double* mean_acc, double* mean_w, double* var_acc, double* var_w,
                                 hipStream_t stream) {
   if (a.n_frames == 0 || a.n_pairs == 0) return hipSuccess;
   hipLaunchKernelGGL(em_assign_kernel, dim3((unsigned)((a.n_frames + kAssignThreads - 1) / kAssignThreads)), dim3(kAssignThreads), 0,
@@ -139,11 +156,15 @@ hipError_t launch_em_accumulate(const EmArgs& a, void* sort_temp, size_t sort_te
   // LSD radix sort is stable: pairs of one row stay in generation (= frame, then density) order
   e = hipcub::DeviceRadixSort::SortPairs(sort_temp, sort_temp_bytes, a.key_mean, keys_sorted, iota, pairs_sorted, (int)a.n_pairs, 0, 32, stream);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((em_sum_kernel<false>), dim3(a.n_mean), dim3(64), 0, stream, a, keys_sorted, pairs_sorted, a.n_mean, mean_acc, mean_w);
+  hipLaunchKernelGGL(em_bounds_kernel, dim3(a.n_mean / 256 + 1), dim3(256), 0, stream, keys_sorted, a.n_pairs, a.n_mean, row_begin);
+  hipLaunchKernelGGL((em_sum_kernel<false>), dim3((unsigned)(((uint64_t)a.n_mean * a.dim + 255) / 256)), dim3(256), 0, stream, a,
+                     row_begin, pairs_sorted, a.n_mean, mean_acc, mean_w);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   e = hipcub::DeviceRadixSort::SortPairs(sort_temp, sort_temp_bytes, a.key_var, keys_sorted, iota, pairs_sorted, (int)a.n_pairs, 0, 32, stream);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((em_sum_kernel<true>), dim3(a.n_var), dim3(64), 0, stream, a, keys_sorted, pairs_sorted, a.n_var, var_acc, var_w);
+  hipLaunchKernelGGL(em_bounds_kernel, dim3(a.n_var / 256 + 1), dim3(256), 0, stream, keys_sorted, a.n_pairs, a.n_var, row_begin);
+  hipLaunchKernelGGL((em_sum_kernel<true>), dim3((unsigned)(((uint64_t)a.n_var * a.dim + 255) / 256)), dim3(256), 0, stream, a,
+                     row_begin, pairs_sorted, a.n_var, var_acc, var_w);
   return hipGetLastError();
 }
 

@@ -27,12 +27,31 @@ __global__ __launch_bounds__(kExactThreads) void gmm_exact_kernel(
     const float* __restrict__ feats, uint64_t n_frames, uint32_t dim, uint32_t n_states,
     const uint32_t* __restrict__ dens_off, const double* __restrict__ means, const double* __restrict__ inv_vars,
     const double* __restrict__ norm, const double* __restrict__ logw, double* __restrict__ out, uint32_t ld,
-    uint32_t states_per_split) {
+    uint32_t states_per_split, GmmExactList L) {
   extern __shared__ float xs[];  // generic-dim path: [dim][kExactThreads]
   const uint32_t D = DS ? DS : dim;
-  const uint64_t f = (uint64_t)blockIdx.x * kExactThreads + threadIdx.x;
-  const bool valid = f < n_frames;
-  const float* xrow = feats + (valid ? f : 0) * D;
+  // dense: block x = 256 consecutive frames, block y = a state range.  listed (L.states != null): block x = up to 256
+  // frames of ONE utterance, scored for the states of that utterance's list only (the forced aligner's automaton)
+  uint64_t f, f_out;
+  bool valid;
+  uint32_t s0, s1;
+  if (L.states) {
+    const uint32_t b = L.blk_first + blockIdx.x;
+    f = L.blk_frame0[b] + threadIdx.x;
+    valid = threadIdx.x < L.blk_frames[b];
+    f_out = f - L.frame_base;
+    s0 = L.list_off[L.blk_list[b]];
+    s1 = L.list_off[L.blk_list[b] + 1];
+    if (!valid) { f = L.blk_frame0[b]; f_out = 0; }
+  } else {
+    f = (uint64_t)blockIdx.x * kExactThreads + threadIdx.x;
+    valid = f < n_frames;
+    if (!valid) f = 0;
+    f_out = f;
+    s0 = blockIdx.y * states_per_split;
+    s1 = (s0 + states_per_split < n_states) ? s0 + states_per_split : n_states;
+  }
+  const float* xrow = feats + f * D;
   double xr[DS ? DS : 1];
   if (DS) {
 #pragma unroll
@@ -40,11 +59,10 @@ __global__ __launch_bounds__(kExactThreads) void gmm_exact_kernel(
   } else {
     for (uint32_t d = 0; d < D; d++) xs[d * kExactThreads + threadIdx.x] = xrow[d];
   }
-  const uint32_t s0 = blockIdx.y * states_per_split;
-  const uint32_t s1 = (s0 + states_per_split < n_states) ? s0 + states_per_split : n_states;
   const uint32_t D2 = D - (D & 1u);
 
-  for (uint32_t s = s0; s < s1; s++) {
+  for (uint32_t si = s0; si < s1; si++) {
+    const uint32_t s = L.states ? L.states[si] : si;
     const uint32_t c0 = dens_off[s], c1 = dens_off[s + 1];
     double best = SUM ? 0.0 : 1e10;  // Mixtures.cpp:699 / :721
     for (uint32_t c = c0; c < c1; c++) {
@@ -86,30 +104,44 @@ __global__ __launch_bounds__(kExactThreads) void gmm_exact_kernel(
       if (SUM) best += exp(-1 * score);
       else if (score < best) best = score;
     }
-    if (valid) out[f * ld + s] = SUM ? -1 * log(best) : best;
+    if (valid) out[f_out * ld + s] = SUM ? -1 * log(best) : best;
   }
 }
 
 template <int DS>
-static hipError_t launch_d(const GmmExactArgs& a, bool sum, uint32_t n_splits, hipStream_t stream) {
-  const dim3 grid((unsigned)((a.n_frames + kExactThreads - 1) / kExactThreads), n_splits), block(kExactThreads);
+static hipError_t launch_d(const GmmExactArgs& a, bool sum, uint32_t n_splits, const GmmExactList& L, uint32_t n_blocks,
+                           hipStream_t stream) {
+  const dim3 grid(L.states ? n_blocks : (unsigned)((a.n_frames + kExactThreads - 1) / kExactThreads), L.states ? 1 : n_splits),
+      block(kExactThreads);
   const size_t shmem = DS ? 0 : (size_t)a.dim * kExactThreads * sizeof(float);
   if (sum)
     hipLaunchKernelGGL((gmm_exact_kernel<DS, true>), grid, block, shmem, stream, a.feats, a.n_frames, a.dim, a.n_states,
-                       a.dens_off, a.means, a.inv_vars, a.norm, a.logw, a.out, a.ld, a.states_per_split);
+                       a.dens_off, a.means, a.inv_vars, a.norm, a.logw, a.out, a.ld, a.states_per_split, L);
   else
     hipLaunchKernelGGL((gmm_exact_kernel<DS, false>), grid, block, shmem, stream, a.feats, a.n_frames, a.dim, a.n_states,
-                       a.dens_off, a.means, a.inv_vars, a.norm, a.logw, a.out, a.ld, a.states_per_split);
+                       a.dens_off, a.means, a.inv_vars, a.norm, a.logw, a.out, a.ld, a.states_per_split, L);
   return hipGetLastError();
 }
 
 hipError_t launch_gmm_exact(const GmmExactArgs& a, bool sum, uint32_t n_splits, hipStream_t stream) {
   if (a.n_frames == 0) return hipSuccess;
+  const GmmExactList none{};
   switch (a.dim) {
-    case 39: return launch_d<39>(a, sum, n_splits, stream);
-    case 25: return launch_d<25>(a, sum, n_splits, stream);
-    default: return launch_d<0>(a, sum, n_splits, stream);
+    case 39: return launch_d<39>(a, sum, n_splits, none, 0, stream);
+    case 25: return launch_d<25>(a, sum, n_splits, none, 0, stream);
+    default: return launch_d<0>(a, sum, n_splits, none, 0, stream);
   }
 }
+
+hipError_t launch_gmm_exact_listed(const GmmExactArgs& a, bool sum, const GmmExactList& L, uint32_t n_blocks, hipStream_t stream) {
+  if (n_blocks == 0) return hipSuccess;
+  switch (a.dim) {
+    case 39: return launch_d<39>(a, sum, 1, L, n_blocks, stream);
+    case 25: return launch_d<25>(a, sum, 1, L, n_blocks, stream);
+    default: return launch_d<0>(a, sum, 1, L, n_blocks, stream);
+  }
+}
+
+int gmm_exact_frames_per_block() { return kExactThreads; }
 
 }  // namespace srgpu

@@ -38,6 +38,20 @@ struct GmmExactArgs {
   uint32_t states_per_split; // grid.y splits the state range
 };
 hipError_t launch_gmm_exact(const GmmExactArgs& a, bool sum, uint32_t n_splits, hipStream_t stream);
+// listed mode: only the (frame, state) pairs a forced alignment can touch.  Block b covers blk_frames[b] (<= 256) frames
+// of one utterance starting at absolute frame blk_frame0[b] (a.feats = the corpus' first frame) and scores the states
+// states[list_off[blk_list[b]] .. list_off[blk_list[b] + 1]) into out[(frame - frame_base) * ld + state].
+struct GmmExactList {
+  const uint64_t* blk_frame0;
+  const uint32_t* blk_frames;
+  const uint32_t* blk_list;
+  const uint32_t* list_off;
+  const uint32_t* states;   // null: dense mode
+  uint32_t blk_first;
+  uint64_t frame_base;
+};
+hipError_t launch_gmm_exact_listed(const GmmExactArgs& a, bool sum, const GmmExactList& L, uint32_t n_blocks, hipStream_t stream);
+int gmm_exact_frames_per_block();
 
 // ---- exact GMM scoring through a bf16 prefilter (gmm_prefilter.hip) ------------------------------------------------
 struct GmmPrefilterArgs {
@@ -184,7 +198,7 @@ struct EmArgs {
 };
 size_t em_sort_temp_bytes(uint64_t n_pairs);
 hipError_t launch_em_accumulate(const EmArgs& a, void* sort_temp, size_t sort_temp_bytes, uint32_t* iota, uint32_t* keys_sorted,
-                                uint32_t* pairs_sorted, double* mean_acc, double* mean_w, double* var_acc, double* var_w,
-                                hipStream_t stream);
+                                uint32_t* pairs_sorted, uint32_t* row_begin /* [max(n_mean, n_var) + 1] */, double* mean_acc,
+                                double* mean_w, double* var_acc, double* var_w, hipStream_t stream);
 
 }  // namespace srgpu

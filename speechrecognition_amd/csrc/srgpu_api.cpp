@@ -82,6 +82,9 @@ struct sr_model {
   // EM tying (accumulator rows)
   DevBuf<uint32_t> dens_mean, dens_var;
   std::vector<uint32_t> h_dens_off;
+  // host copies of the finalised tables: the kernel-specific packings are built on first use of that kernel
+  std::vector<double> h_means, h_inv_vars, h_norm, h_logw;
+  bool mfma_packed = false, pf_packed = false;
   uint32_t n_mean = 0, n_var = 0;
   // MFMA packing
   int ksteps = 0;
@@ -125,12 +128,13 @@ struct sr_corpus {
   DevBuf<uint32_t> out_words, out_count, out_flags;
   // aligner workspace
   DevBuf<uint16_t> automata, out_states;
-  DevBuf<uint64_t> aut_off, bp_off;
+  DevBuf<uint64_t> aut_off, bp_off, al_blk_frame0;
+  DevBuf<uint32_t> al_list_off, al_states, al_blk_frames, al_blk_list;
   DevBuf<uint8_t> backptr;
   DevBuf<double> out_cost, path_scores;
   // EM accumulation workspace
   DevBuf<uint64_t> pair_off;
-  DevBuf<uint32_t> pair_frame, key_mean, key_var, iota, keys_sorted, pairs_sorted;
+  DevBuf<uint32_t> pair_frame, key_mean, key_var, iota, keys_sorted, pairs_sorted, row_begin;
   DevBuf<double> pair_w, acc_mean, acc_var, w_mean, w_var;
   DevBuf<unsigned char> sort_temp;
 };
@@ -452,6 +456,16 @@ int prof_end(sr_model* m, hipStream_t s, EventPair* ep) {
 int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm_kernel, double* d_out) {
   if (n_frames == 0) return SR_OK;
   EventPair ep{};
+  if (gmm_kernel == SR_GMM_MFMA && !m->mfma_packed) {
+    int rc = pack_model(m, m->h_dens_off.data(), m->h_means.data(), m->h_inv_vars.data(), m->h_norm.data(), m->h_logw.data());
+    if (rc) return rc;
+    m->mfma_packed = true;
+  }
+  if (gmm_kernel == SR_GMM_PREFILTER && !m->pf_packed) {
+    int rc = pack_prefilter(m, m->h_dens_off.data(), m->h_means.data(), m->h_inv_vars.data(), m->h_norm.data(), m->h_logw.data());
+    if (rc) return rc;
+    m->pf_packed = true;
+  }
   if (gmm_kernel == SR_GMM_MFMA) {
     const uint32_t tile = gmm_mfma_frames_per_tile(m->ksteps);
     const uint32_t nx = (uint32_t)((n_frames + tile - 1) / tile);
@@ -602,12 +616,19 @@ int sr_model_create(int device, uint32_t dim, uint32_t n_states, const uint32_t*
       rc = fail(SR_EHIP, "model upload: %s", hipGetErrorString(e));
       break;
     }
-    rc = pack_model(m, dens_off, means, inv_vars, norm, logw);
-    if (rc == SR_OK) rc = pack_prefilter(m, dens_off, means, inv_vars, norm, logw);
+    {
+      uint32_t mx = 0;
+      for (uint32_t s = 0; s < n_states; s++) mx = std::max(mx, dens_off[s + 1] - dens_off[s]);
+      m->max_dens = std::max(1u, mx);
+      m->h_dens_off.assign(dens_off, dens_off + n_states + 1);
+      m->h_means.assign(means, means + C * dim);
+      m->h_inv_vars.assign(inv_vars, inv_vars + C * dim);
+      m->h_norm.assign(norm, norm + C);
+      m->h_logw.assign(logw, logw + C);
+    }
     if (rc == SR_OK) {
       std::vector<uint32_t> ident(C);
       std::iota(ident.begin(), ident.end(), 0u);
-      m->h_dens_off.assign(dens_off, dens_off + n_states + 1);
       m->n_mean = m->n_var = (uint32_t)C;
       if ((e = m->dens_mean.upload(ident.data(), C)) != hipSuccess || (e = m->dens_var.upload(ident.data(), C)) != hipSuccess)
         rc = fail(SR_EHIP, "tying upload: %s", hipGetErrorString(e));
@@ -686,9 +707,10 @@ int sr_corpus_destroy(sr_corpus* c) {
   if (c->model) { (void)hipSetDevice(c->model->device); (void)hipDeviceSynchronize(); }
   c->feats.release(); c->d_frame_off.release(); c->tb_score.release(); c->tb_word.release(); c->tb_bkp.release();
   c->out_words.release(); c->out_count.release(); c->out_flags.release(); c->automata.release(); c->out_states.release();
-  c->aut_off.release(); c->bp_off.release(); c->backptr.release(); c->out_cost.release(); c->path_scores.release();
+  c->aut_off.release(); c->bp_off.release(); c->al_blk_frame0.release(); c->al_list_off.release(); c->al_states.release();
+  c->al_blk_frames.release(); c->al_blk_list.release(); c->backptr.release(); c->out_cost.release(); c->path_scores.release();
   c->pair_off.release(); c->pair_frame.release(); c->key_mean.release(); c->key_var.release(); c->iota.release();
-  c->keys_sorted.release(); c->pairs_sorted.release(); c->pair_w.release(); c->acc_mean.release(); c->acc_var.release();
+  c->keys_sorted.release(); c->pairs_sorted.release(); c->row_begin.release(); c->pair_w.release(); c->acc_mean.release(); c->acc_var.release();
   c->w_mean.release(); c->w_var.release(); c->sort_temp.release();
   delete c;
   return SR_OK;
@@ -1087,6 +1109,34 @@ static int align_common(sr_model* m, sr_corpus* c, const uint16_t* automata, con
   HIP_TRY(c->out_cost.ensure(U));
   const std::vector<Chunk> chunks = make_chunks(c, m->chunk_frames);
   if ((rc = ensure_score_ws(m, chunks))) return rc;
+  // The aligner reads scores of its automaton's states only (N of S): with a bit-exact kernel requested, score just
+  // those (frame, state) pairs -- the direct-form kernel in listed mode, the same bits as the dense table would hold.
+  // (SR_GMM_MFMA keeps the dense FP64-MFMA table: its rounding differs.)
+  const bool listed = gmm_kernel != SR_GMM_MFMA;
+  std::vector<uint32_t> blk_first_of_utt(U + 1, 0);
+  if (listed) {
+    const uint32_t fpb = (uint32_t)gmm_exact_frames_per_block();
+    std::vector<uint32_t> list_off(U + 1, 0), list_states, blk_frames, blk_list;
+    std::vector<uint64_t> blk_frame0;
+    for (uint32_t u = 0; u < U; u++) {
+      std::vector<uint32_t> st(automata + aut_off[u], automata + aut_off[u + 1]);
+      std::sort(st.begin(), st.end());
+      st.erase(std::unique(st.begin(), st.end()), st.end());
+      list_states.insert(list_states.end(), st.begin(), st.end());
+      list_off[u + 1] = (uint32_t)list_states.size();
+      for (uint64_t f = c->frame_off[u]; f < c->frame_off[u + 1]; f += fpb) {
+        blk_frame0.push_back(f);
+        blk_frames.push_back((uint32_t)std::min<uint64_t>(fpb, c->frame_off[u + 1] - f));
+        blk_list.push_back(u);
+      }
+      blk_first_of_utt[u + 1] = (uint32_t)blk_frame0.size();
+    }
+    HIP_TRY(c->al_list_off.upload(list_off.data(), list_off.size()));
+    HIP_TRY(c->al_states.upload(list_states.data(), list_states.size()));
+    HIP_TRY(c->al_blk_frame0.upload(blk_frame0.data(), blk_frame0.size()));
+    HIP_TRY(c->al_blk_frames.upload(blk_frames.data(), blk_frames.size()));
+    HIP_TRY(c->al_blk_list.upload(blk_list.data(), blk_list.size()));
+  }
   AlignArgs aa{};
   aa.ld = m->ld; aa.frame_off = c->d_frame_off.p; aa.automata = c->automata.p; aa.aut_off = c->aut_off.p;
   aa.tdp_loop = tdp[0]; aa.tdp_forward = tdp[1]; aa.tdp_skip = tdp[2]; aa.silence_state = silence_state;
@@ -1096,7 +1146,22 @@ static int align_common(sr_model* m, sr_corpus* c, const uint16_t* automata, con
     const Chunk& ch = chunks[i];
     const int buf = (int)(i & 1);
     if (i >= 2) HIP_TRY(hipStreamWaitEvent(m->s_gmm, m->ev_consumed[buf], 0));
-    if ((rc = launch_scoring(m, c->feats.p + ch.f0 * m->dim, ch.f1 - ch.f0, gmm_kernel, m->scores[buf].p))) return rc;
+    if (listed) {
+      GmmExactArgs ga{};
+      ga.feats = c->feats.p; ga.n_frames = c->n_frames; ga.dim = m->dim; ga.n_states = m->n_states;
+      ga.dens_off = m->dens_off.p; ga.means = m->means.p; ga.inv_vars = m->inv_vars.p; ga.norm = m->norm.p; ga.logw = m->logw.p;
+      ga.out = m->scores[buf].p; ga.ld = m->ld;
+      GmmExactList gl{};
+      gl.blk_frame0 = c->al_blk_frame0.p; gl.blk_frames = c->al_blk_frames.p; gl.blk_list = c->al_blk_list.p;
+      gl.list_off = c->al_list_off.p; gl.states = c->al_states.p;
+      gl.blk_first = blk_first_of_utt[ch.u0]; gl.frame_base = ch.f0;
+      EventPair eg{};
+      if ((rc = prof_begin(m, m->s_gmm, 0, &eg))) return rc;
+      HIP_TRY(launch_gmm_exact_listed(ga, !m->max_approx, gl, blk_first_of_utt[ch.u1] - blk_first_of_utt[ch.u0], m->s_gmm));
+      if ((rc = prof_end(m, m->s_gmm, &eg))) return rc;
+    } else if ((rc = launch_scoring(m, c->feats.p + ch.f0 * m->dim, ch.f1 - ch.f0, gmm_kernel, m->scores[buf].p))) {
+      return rc;
+    }
     HIP_TRY(hipEventRecord(m->ev_scored[buf], m->s_gmm));
     HIP_TRY(hipStreamWaitEvent(m->s_search, m->ev_scored[buf], 0));
     aa.scores = m->scores[buf].p; aa.frame_base = ch.f0; aa.utt_first = ch.u0; aa.n_utts = ch.u1 - ch.u0;
@@ -1207,6 +1272,7 @@ int sr_accumulate_corpus(sr_model* m, sr_corpus* c, const uint16_t* states, int 
   }
   const size_t temp = em_sort_temp_bytes(n_pairs);
   HIP_TRY(c->sort_temp.ensure(temp));
+  HIP_TRY(c->row_begin.ensure((size_t)std::max(m->n_mean, m->n_var) + 1));
   HIP_TRY(c->acc_mean.ensure((size_t)m->n_mean * D)); HIP_TRY(c->w_mean.ensure(m->n_mean));
   HIP_TRY(c->acc_var.ensure((size_t)m->n_var * D)); HIP_TRY(c->w_var.ensure(m->n_var));
   EmArgs a{};
@@ -1217,7 +1283,7 @@ int sr_accumulate_corpus(sr_model* m, sr_corpus* c, const uint16_t* states, int 
   a.pair_frame = c->pair_frame.p; a.pair_w = c->pair_w.p; a.key_mean = c->key_mean.p; a.key_var = c->key_var.p;
   EventPair ep{};
   if ((rc = prof_begin(m, m->s_gmm, 1, &ep))) return rc;
-  HIP_TRY(launch_em_accumulate(a, c->sort_temp.p, temp, c->iota.p, c->keys_sorted.p, c->pairs_sorted.p, c->acc_mean.p, c->w_mean.p,
+  HIP_TRY(launch_em_accumulate(a, c->sort_temp.p, temp, c->iota.p, c->keys_sorted.p, c->pairs_sorted.p, c->row_begin.p, c->acc_mean.p, c->w_mean.p,
                                c->acc_var.p, c->w_var.p, m->s_gmm));
   if ((rc = prof_end(m, m->s_gmm, &ep))) return rc;
   HIP_TRY(hipStreamSynchronize(m->s_gmm));
