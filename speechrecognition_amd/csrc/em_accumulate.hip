@@ -92,6 +92,36 @@ __global__ __launch_bounds__(kAssignThreads) void em_assign_kernel(EmArgs a) {
   }
 }
 
+// out[t] = MixtureModel::score(frame t, states[t]) (Trainer::calc_am_score's summand, Training.cpp:605): one thread per
+// frame, direct form in the reference's operation order -- the same bits as the dense table's entry
+__global__ __launch_bounds__(kAssignThreads) void path_score_direct_kernel(EmArgs a, double* out) {
+  const uint64_t t = (uint64_t)blockIdx.x * kAssignThreads + threadIdx.x;
+  if (t >= a.n_frames) return;
+  const uint32_t D = a.dim;
+  const float* x = a.feats + t * D;
+  const uint32_t s = a.states[t], c0 = a.dens_off[s], c1 = a.dens_off[s + 1];
+  if (a.max_approx) {
+    double best = 1e10;
+    for (uint32_t c = c0; c < c1; c++) {
+      const double sc = em_density_score(x, a.means + (uint64_t)c * D, a.inv_vars + (uint64_t)c * D, a.norm[c], a.logw[c], D);
+      if (sc < best) best = sc;
+    }
+    out[t] = best;
+  } else {
+    double sum = 0.0;  // sum_score (Mixtures.cpp:719-728)
+    for (uint32_t c = c0; c < c1; c++)
+      sum += exp(-1 * em_density_score(x, a.means + (uint64_t)c * D, a.inv_vars + (uint64_t)c * D, a.norm[c], a.logw[c], D));
+    out[t] = -1 * log(sum);
+  }
+}
+
+hipError_t launch_path_scores_direct(const EmArgs& a, double* out, hipStream_t stream) {
+  if (a.n_frames == 0) return hipSuccess;
+  hipLaunchKernelGGL(path_score_direct_kernel, dim3((unsigned)((a.n_frames + kAssignThreads - 1) / kAssignThreads)),
+                     dim3(kAssignThreads), 0, stream, a, out);
+  return hipGetLastError();
+}
+
 // row_begin[r] = first pair whose key is >= r (r = 0 .. n_rows): one thread per row, a binary search each
 __global__ __launch_bounds__(256) void em_bounds_kernel(const uint32_t* sorted_keys, uint64_t n_pairs, uint32_t n_rows,
                                                         uint32_t* row_begin) {

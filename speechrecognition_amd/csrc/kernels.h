@@ -197,6 +197,8 @@ struct EmArgs {
   uint32_t* pair_frame; double* pair_w; uint32_t* key_mean; uint32_t* key_var;  // [n_pairs] workspace
 };
 size_t em_sort_temp_bytes(uint64_t n_pairs);
+// out[t] = score(frame t, a.states[t]); uses feats, n_frames, dim, states, dens_off, means, inv_vars, norm, logw, max_approx
+hipError_t launch_path_scores_direct(const EmArgs& a, double* out, hipStream_t stream);
 hipError_t launch_em_accumulate(const EmArgs& a, void* sort_temp, size_t sort_temp_bytes, uint32_t* iota, uint32_t* keys_sorted,
                                 uint32_t* pairs_sorted, uint32_t* row_begin /* [max(n_mean, n_var) + 1] */, double* mean_acc,
                                 double* mean_w, double* var_acc, double* var_w, hipStream_t stream);

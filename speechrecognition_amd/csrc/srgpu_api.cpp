@@ -1204,6 +1204,17 @@ int sr_path_scores_corpus(sr_model* m, sr_corpus* c, const uint16_t* states, int
     if (states[f] >= m->n_states) return fail(SR_EINVAL, "frame %llu: state %u >= n_states", (unsigned long long)f, states[f]);
   HIP_TRY(c->out_states.upload(states, F));
   HIP_TRY(c->path_scores.ensure(F));
+  if (gmm_kernel != SR_GMM_MFMA) {  // bit-exact kernels: score the F (frame, state) pairs directly, no dense table
+    EmArgs a{};
+    a.feats = c->feats.p; a.n_frames = F; a.dim = m->dim; a.states = c->out_states.p;
+    a.dens_off = m->dens_off.p; a.means = m->means.p; a.inv_vars = m->inv_vars.p; a.norm = m->norm.p; a.logw = m->logw.p;
+    a.max_approx = m->max_approx;
+    HIP_TRY(launch_path_scores_direct(a, c->path_scores.p, m->s_gmm));
+    HIP_TRY(hipStreamSynchronize(m->s_gmm));
+    HIP_TRY(hipMemcpy(out, c->path_scores.p, sizeof(double) * F, hipMemcpyDeviceToHost));
+    if (m->profiling) m->prof.frames += F;
+    return SR_OK;
+  }
   const size_t step = m->chunk_frames;
   HIP_TRY(m->scores[0].ensure((size_t)std::min<uint64_t>(F, step) * m->ld));
   for (uint64_t f = 0; f < F; f += step) {
