@@ -1,26 +1,30 @@
-// gmm_prefilter.hip -- exact max-approx GMM scoring with ~30x fewer FP64 flops: a bf16 MFMA prefilter that can
+// gmm_prefilter.hip -- exact max-approx GMM scoring with ~30x fewer FP64 flops: an fp16 MFMA prefilter that can
 // only OVER-select, followed by an FP64 refinement of the selected densities in the reference's operation order.
 //
 // MixtureModel::min_score (sietill/Mixtures.cpp:696-713) needs, per (frame, state), only the minimum density
 // score.  Kernel P computes every density score in the GEMM form of gmm_mfma.hip,
 //     score(c, t) = konst_c + sum_k a_ck b_kt,   a_c = [1/(2 var); -mu/var],  b_t = [x^2; x],
-// on the bf16 matrix cores: a and b are split in two bf16 terms each (v ~ v_hi + v_lo, round to nearest), the
-// products hi*hi + hi*lo + lo*hi are accumulated in fp32, and konst_c enters through three spare k slots as an
-// exact 3-term bf16 expansion (24 bits) times 1.  Error bound, with u16 = 2^-16, u24 = 2^-24:
-//   * operand splitting: each 2-term split has relative residual <= 2^-17 (hi: 8 bits, lo: 8 more, plus sign), the
-//     dropped lo*lo product is <= 2^-18 |a b|:                      <= 3.03 u16 * sum_k |a_k b_k|
-//   * bf16 x bf16 products are exact in fp32; <= 288 + 3 fp32 additions, each off by u24 of a partial sum that
-//     never exceeds |konst| + sum |a b| (first order):               <= 291 u24 * (|konst_c| + sum_k |a_k b_k|)
-// and sum_k |a_k b_k| <= |a_c|_2 |b_t|_2.  So with  eps = kKappa |a|_2 |b|_2 + kKonst |konst|  (kKappa = 1e-4 against
-// 6.4e-5 needed, kKonst = 3e-5 against 1.74e-5; |a|, |konst| = the largest over the state's densities, rounded
-// up on the host; |b| computed per frame, rounded up) every density whose approximation lies within 2*eps of the
-// state's smallest approximation -- plus anything that is not a number -- is a candidate, and the true arg-min is
-// provably among them.  P writes one 32-bit candidate mask per (frame, state): ~1.01 bits set on average.
+// on the fp16 matrix cores: both operands rounded ONCE to fp16 (11 significant bits), one MFMA per k-step, fp32
+// accumulation; konst_c enters through three spare k slots as an exact 3-term fp16 expansion (33 bits) times 1.  The
+// model side is scaled by a power of two sA (host: largest coefficient or constant -> below 2^14) so that fp16's
+// narrow exponent range is used well; scores, norms and the candidate test stay in scaled units.  Error bound:
+//   |delta a_k| <= 2^-11 |a_k| + 2^-25 / sA (subnormal spacing), |delta b_k| <= 2^-11 |b_k| + 2^-25; products of two
+//   fp16 values are exact in fp32; <= 81 + 3 fp32 additions, each off by 2^-24 of a partial sum that never exceeds
+//   |konst| + sum |a b| (first order):
+//   |approx - exact| <= (2^-10 (1 + 2^-12) + 87 * 2^-24) |a||b| + 87 * 2^-24 |konst| + 2^-25 (|b|_1 / sA + |a|_1) (1 + 2^-11)
+// -> eps = kKappa16 |a||b| + kKonst16 |konst| + kAbs16 (|b| / sA + |a|),  kKappa16 = 1.05e-3 (needed 9.82e-4),
+//    kKonst16 = 1e-5 (5.2e-6), kAbs16 = 3.1e-8 * sqrt(2 * 46) (|v|_1 <= sqrt(K) |v|_2, needed 2.98e-8 * sqrt(K));
+//    |a|, |konst| = the largest over the state's densities, rounded up on the host; |b| per frame, rounded up.
+// Every density whose approximation lies within 2*eps of the state's smallest approximation -- plus anything that is
+// not a number -- is a candidate; the true arg-min is provably among them.  A feature beyond fp16's range
+// (|x| > 255) turns its frame's scores into inf/NaN: every density stays a candidate.  P writes one 32-bit candidate
+// mask per (frame, state): 1.09 bits set on average on the bench model.
+// (Measured alternative, removed again: both operands split in two bf16 terms, three products -- a 7x tighter bound,
+// 1.01 candidates, but twice the prefilter time for 20 % less refinement time.)
 //
 // Kernel R evaluates only the candidates, in FP64, replaying density_score_sse's operation order
 // (Mixtures.cpp:645-690): the minimum over the candidates is the minimum over all densities, bit for bit what
-// MixtureModel::score returns.  P is MFMA/LDS-DMA bound (bf16), R is FP64-VALU/LDS bound with about one density
-// per (frame, state) instead of thirty-two.
+// MixtureModel::score returns.
 //
 // Limits of this path: max-approx only, <= 128 densities per mixture (a mixture of more than 32 spans 2 or 4
 // consecutive 32-slot pseudo-states), dim <= 46 (K = 2*dim + 3 <= 96); any other model is scored by the exact FP64
@@ -39,200 +43,17 @@
 namespace srgpu {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
 static constexpr int kPWaves = 4;          // waves per workgroup (P)
-static constexpr int kPStageBlocks = 4;    // 16-row model blocks per LDS stage
 static constexpr int kGroupBlocks = 8;     // every 4-state group is padded to 8 blocks = 32 density slots per state
-static constexpr float kKappa = 1.0e-4f;   // eps = kKappa * |a| * |b| + kKonst * |konst|   (bound derived above)
-static constexpr float kKonst = 3.0e-5f;
-
-__device__ inline uint32_t pack_bf16x2(float lo, float hi) {
-  const __bf16 l = (__bf16)lo, h = (__bf16)hi;  // v_cvt_pk_bf16_f32: round to nearest even
-  return (uint32_t)__builtin_bit_cast(uint16_t, l) | ((uint32_t)__builtin_bit_cast(uint16_t, h) << 16);
-}
-__device__ inline float bf16_round(float v) { return (float)(__bf16)v; }
 
 // ---- kernel P ----------------------------------------------------------------------------------------------
-// apack layout: [block][ks][part: 0 = hi, 1 = lo][lane][8 bf16]; row r of a block = density (r & 3) + 4*block_in_group of
-// state slot (r >> 2), so that a lane's four accumulator registers (rows 4*(lane>>4) + reg) are four densities of ONE
-// state slot for ONE frame (column lane & 15).
-template <int KS32, int NB>
-__global__ __launch_bounds__(kPWaves * 64, 3) void gmm_prefilter_kernel(GmmPrefilterArgs a) {
-  constexpr int kBlockBytes = KS32 * 2 * 1024;
-  constexpr int kStageBytes = kPStageBlocks * kBlockBytes;
-  constexpr int kChunksPerStage = kStageBytes / 1024;
-  constexpr int kTileFrames = kPWaves * NB * 16;
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * kStageBytes];
-  static_assert((size_t)kTileFrames * (16 * KS32) * sizeof(float) <= sizeof(lds), "feature tile (dim < 16*KS32) must fit the stage buffers");
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int g = lane >> 4, c = lane & 15;
-  uint32_t x, y;
-  {
-    const uint32_t id = blockIdx.x;
-    if ((a.ny & 7u) == 0) { const uint32_t j = id >> 3; y = (id & 7u) + 8u * (j / a.nx); x = j % a.nx; }
-    else { y = id / a.nx; x = id % a.nx; }
-  }
-  const uint32_t g0 = a.split_begin[y], g1 = a.split_begin[y + 1];  // group range of this workgroup
-  const uint64_t frame0 = (uint64_t)x * kTileFrames + (uint64_t)wave * (NB * 16);
-
-  // ---- B fragments (hi / lo bf16) and |b| per frame ---------------------------------------------------------
-  uint4 bh[NB][KS32], bl[NB][KS32];
-  float bnorm[NB];
-  {
-    float* fl = reinterpret_cast<float*>(lds);
-    const uint64_t tile_first = (uint64_t)x * kTileFrames;
-    const uint64_t tile_frames = (a.n_frames - tile_first < (uint64_t)kTileFrames) ? a.n_frames - tile_first : kTileFrames;
-    const uint32_t n_floats = (uint32_t)tile_frames * a.dim;
-    const float* src = a.feats + tile_first * a.dim;
-    for (uint32_t i = threadIdx.x; i < n_floats; i += kPWaves * 64) fl[i] = src[i];
-    __syncthreads();
-#pragma unroll
-    for (int nb = 0; nb < NB; nb++) {
-      const uint32_t row = (uint32_t)wave * (NB * 16) + nb * 16 + c;
-      const bool valid = row < tile_frames;
-      const float* xr = fl + (valid ? row : 0u) * a.dim;
-      float n2 = 0.0f;
-#pragma unroll
-      for (int ks = 0; ks < KS32; ks++) {
-        float hi[8], lo[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-          const uint32_t k = 32u * ks + 8u * g + j, d = k >> 1;
-          const double xd = (valid && d < a.dim) ? (double)xr[d < a.dim ? d : 0u] : 0.0;
-          double b = (k & 1u) ? xd : xd * xd;  // k = 2d -> x^2 (exact in double), 2d+1 -> x
-          n2 += (float)(b * b);
-          if (valid && k >= 2u * a.dim && k < 2u * a.dim + 3u) b = 1.0;  // the three konst slots; not part of |b|
-          const float h = bf16_round((float)b);
-          hi[j] = h;
-          lo[j] = (float)(b - (double)h);
-        }
-        bh[nb][ks] = make_uint4(pack_bf16x2(hi[0], hi[1]), pack_bf16x2(hi[2], hi[3]), pack_bf16x2(hi[4], hi[5]), pack_bf16x2(hi[6], hi[7]));
-        bl[nb][ks] = make_uint4(pack_bf16x2(lo[0], lo[1]), pack_bf16x2(lo[2], lo[3]), pack_bf16x2(lo[4], lo[5]), pack_bf16x2(lo[6], lo[7]));
-      }
-      n2 += __shfl_xor(n2, 16);
-      n2 += __shfl_xor(n2, 32);
-      bnorm[nb] = sqrtf(n2) * 1.0001f;  // rounded up: fp32 summation of <= 92 positive terms
-    }
-    __syncthreads();
-  }
-
-  auto issue_stage = [&](uint32_t stage_first_block, int buf) {
-#pragma unroll
-    for (int i = 0; i < (kChunksPerStage + kPWaves - 1) / kPWaves; i++) {
-      const int chunk = i * kPWaves + wave;
-      if (chunk < kChunksPerStage) {
-        const unsigned char* src = a.apack + (uint64_t)stage_first_block * kBlockBytes + (uint64_t)chunk * 1024 + lane * 16;
-        unsigned char* dst = lds + buf * kStageBytes + chunk * 1024;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-      }
-    }
-  };
-
-  // Stage s covers blocks [g0*8 + 4s, +4): two stages per group.  The loop is software-pipelined at k-step
-  // granularity: the two A fragments (hi, lo) of step t+1 are read from LDS before the six MFMAs of step t issue, and at
-  // the last step of a stage the wave joins the barrier for the NEXT stage first, so that the pipeline runs across
-  // stage boundaries and the LDS-DMA of stage s+2 goes into the buffer everybody has just finished reading.
-  const uint32_t n_stages = (g1 - g0) * (kGroupBlocks / kPStageBlocks);
-  constexpr int kDmaPerWave = (kChunksPerStage + kPWaves - 1) / kPWaves;
-  static_assert(kChunksPerStage % kPWaves == 0, "every wave issues the same number of LDS-DMA pieces per stage");
-  auto frag = [&](int buf, int j, int ks, int part) -> bf16x8 {
-    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + buf * kStageBytes + j * kBlockBytes + (ks * 2 + part) * 1024 + lane * 16));
-  };
-  if (n_stages > 0) issue_stage(g0 * kGroupBlocks, 0);
-  if (n_stages > 1) issue_stage(g0 * kGroupBlocks + kPStageBlocks, 1);
-  if (n_stages > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | kDmaPerWave);  // vmcnt(kDmaPerWave): stage 0 has landed
-  else __builtin_amdgcn_s_waitcnt(0x0F70);
-  __syncthreads();
-  bf16x8 ah_c, al_c, ah_n, al_n;
-  if (n_stages > 0) { ah_c = frag(0, 0, 0, 0); al_c = frag(0, 0, 0, 1); }
-  uint32_t s = 0;
-  for (uint32_t grp = g0; grp < g1; grp++) {
-    v4f ap[NB][kGroupBlocks];
-#pragma unroll
-    for (int half = 0; half < kGroupBlocks / kPStageBlocks; half++, s++) {
-      const int buf = s & 1;
-#pragma unroll
-      for (int j = 0; j < kPStageBlocks; j++) {
-        v4f acc[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++) acc[nb] = (v4f){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < KS32; ks++) {
-          if (j == kPStageBlocks - 1 && ks == KS32 - 1) {
-            if (s + 1 < n_stages) {  // workgroup-uniform
-              __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): stage s+1 landed, my reads of stage s returned
-              __syncthreads();
-              if (s + 2 < n_stages) issue_stage(g0 * kGroupBlocks + (s + 2) * kPStageBlocks, buf);
-              ah_n = frag(buf ^ 1, 0, 0, 0);
-              al_n = frag(buf ^ 1, 0, 0, 1);
-            }
-          } else {
-            const int jn = (ks == KS32 - 1) ? j + 1 : j, kn = (ks == KS32 - 1) ? 0 : ks + 1;
-            ah_n = frag(buf, jn, kn, 0);
-            al_n = frag(buf, jn, kn, 1);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int nb = 0; nb < NB; nb++)
-            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah_c, __builtin_bit_cast(bf16x8, bh[nb][ks]), acc[nb], 0, 0, 0);
-#pragma unroll
-          for (int nb = 0; nb < NB; nb++)
-            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah_c, __builtin_bit_cast(bf16x8, bl[nb][ks]), acc[nb], 0, 0, 0);
-#pragma unroll
-          for (int nb = 0; nb < NB; nb++)
-            acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al_c, __builtin_bit_cast(bf16x8, bh[nb][ks]), acc[nb], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          ah_c = ah_n;
-          al_c = al_n;
-        }
-#pragma unroll
-        for (int nb = 0; nb < NB; nb++) ap[nb][half * kPStageBlocks + j] = acc[nb];
-      }
-    }
-    // ---- candidate mask of state slot g of this group, for the lane's frame(s) -------------------------------------
-    // largest |a| and |konst| over the state's densities (rounded up on the host)
-    const float2 nk = reinterpret_cast<const float2*>(a.grp_anorm)[4u * grp + g];
-#pragma unroll
-    for (int nb = 0; nb < NB; nb++) {
-      // v_min3_f32 directly: the hardware minimum already drops (quiet) NaNs; fminf() would canonicalise every operand
-      // first (one v_max_f32 each).  Should a NaN survive, the limit is NaN and every density stays a candidate.
-      float amin = __builtin_huge_valf();
-#pragma unroll
-      for (int j = 0; j < kGroupBlocks; j++) {
-        asm("v_min3_f32 %0, %0, %1, %2" : "+v"(amin) : "v"(ap[nb][j][0]), "v"(ap[nb][j][1]));
-        asm("v_min3_f32 %0, %0, %1, %2" : "+v"(amin) : "v"(ap[nb][j][2]), "v"(ap[nb][j][3]));
-      }
-      if (a.chunks >= 2) { const float o = __shfl_xor(amin, 16); asm("v_min_f32 %0, %0, %1" : "+v"(amin) : "v"(o)); }  // the other chunk(s) of the state
-      if (a.chunks >= 4) { const float o = __shfl_xor(amin, 32); asm("v_min_f32 %0, %0, %1" : "+v"(amin) : "v"(o)); }
-      const float limit = amin + 2.0f * ((kKappa * 1.001f) * nk.x * bnorm[nb] + kKonst * nk.y);
-      // mask = 2*mask + !(value > limit), densities in descending order: one compare + one add-with-carry per density.
-      // NaN (bad variance) or an infinite limit: stay candidates.
-      uint32_t mask = 0;
-#pragma unroll
-      for (int j = kGroupBlocks - 1; j >= 0; j--)
-#pragma unroll
-        for (int i = 3; i >= 0; i--)
-          asm("v_cmp_ngt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(ap[nb][j][i]), "v"(limit) : "vcc");
-      const uint64_t f = frame0 + (uint64_t)nb * 16 + c;
-      if (f < a.n_frames) a.mask[((uint64_t)grp * a.n_frames + f) * 4u + g] = mask;  // 256 contiguous bytes per wave
-    }
-  }
-}
-
-// ---- kernel P, fp16 single-product variant ---------------------------------------------------------------------
-// Same structure, a third of the matrix work: both operands rounded ONCE to fp16 (11 significant bits), one MFMA per
-// k-step.  The model side is scaled by a power of two sA (host: largest coefficient or constant -> below 2^14) so
-// that fp16's narrow exponent range is used well; scores, norms and the candidate test stay in scaled units.
-//   |delta a_k| <= 2^-11 |a_k| + 2^-25 / sA (subnormal spacing), |delta b_k| <= 2^-11 |b_k| + 2^-25; products of two
-//   fp16 values are exact in fp32; <= 81 + 3 fp32 additions; konst as an exact 3-term fp16 expansion (33 bits):
-//   |approx - exact| <= (2^-10 (1 + 2^-12) + 87 * 2^-24) |a||b| + 87 * 2^-24 |konst| + 2^-25 (|b|_1 / sA + |a|_1) (1 + 2^-11)
-// -> eps = kKappa16 |a||b| + kKonst16 |konst| + kAbs16 (|b| / sA + |a|),  kKappa16 = 1.05e-3 (needed 9.82e-4),
-//    kKonst16 = 1e-5 (5.2e-6), kAbs16 = 3.1e-8 * sqrt(2 * 46) (|v|_1 <= sqrt(K) |v|_2, needed 2.98e-8 * sqrt(K)).
-// A feature beyond fp16's range (|x| > 255) turns its frame's scores into inf/NaN: every density stays a candidate.
-// About 1.07 candidates per (frame, state) on the bench model instead of 1.01, for a third of the MFMA time.
+// apack layout: [group][8 blocks][k-step of 32][lane][8 fp16] = the A operand of v_mfma_f32_16x16x32_f16 (lane l holds
+// row l & 15, k = 32*ks + 8*(l >> 4) + j); row r of a block = density (r & 3) + 4*block of state slot (r >> 2), so that
+// a lane's four accumulator registers (rows 4*(lane>>4) + reg) are four densities of ONE state slot for ONE frame
+// (column lane & 15).  One LDS stage = one group = 8 blocks, LDS-DMA double buffered; the A fragment of step t+1 is
+// read before the MFMAs of step t issue, and at the last step of a stage the wave joins the barrier for the NEXT
+// stage first, so that the pipeline runs across stage boundaries and the LDS-DMA of stage s+2 goes into the buffer
+// everybody has just finished reading.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 static constexpr float kKappa16 = 1.05e-3f, kKonst16 = 1.0e-5f, kAbs16 = 3.0e-7f;
 
@@ -241,7 +62,6 @@ __device__ inline uint32_t pack_f16x2(float lo, float hi) {
   return (uint32_t)__builtin_bit_cast(uint16_t, l) | ((uint32_t)__builtin_bit_cast(uint16_t, h) << 16);
 }
 
-// apack16 layout: [block][ks][lane][8 fp16] (rows as in the bf16 kernel); one stage = one group = 8 blocks.
 template <int KS32, int NB>
 __global__ __launch_bounds__(kPWaves * 64, (NB <= 2 ? 3 : 2)) void gmm_prefilter16_kernel(GmmPrefilterArgs a) {
   constexpr int kBlockBytes = KS32 * 1024;
@@ -317,7 +137,7 @@ __global__ __launch_bounds__(kPWaves * 64, (NB <= 2 ? 3 : 2)) void gmm_prefilter
     return __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(lds + buf * kStageBytes + j * kBlockBytes + ks * 1024 + lane * 16));
   };
 
-  // one stage per group; A fragments are read one k-step ahead, across the stage boundary too (see the bf16 kernel)
+  // one stage per group; A fragments are read one k-step ahead, across the stage boundary too
   const uint32_t n_stages = g1 - g0;
   if (n_stages > 0) issue_stage(g0, 0);
   if (n_stages > 1) issue_stage(g0 + 1, 1);
@@ -386,24 +206,15 @@ __global__ __launch_bounds__(kPWaves * 64, (NB <= 2 ? 3 : 2)) void gmm_prefilter
 
 hipError_t launch_gmm_prefilter(const GmmPrefilterArgs& a, int ks32, hipStream_t stream) {
   const dim3 grid(a.nx * a.ny), block(kPWaves * 64);
-  if (a.fp16) {
-    switch (ks32) {
-      case 1: hipLaunchKernelGGL((gmm_prefilter16_kernel<1, SR_P16_NB>), grid, block, 0, stream, a); break;
-      case 2: hipLaunchKernelGGL((gmm_prefilter16_kernel<2, SR_P16_NB>), grid, block, 0, stream, a); break;
-      case 3: hipLaunchKernelGGL((gmm_prefilter16_kernel<3, SR_P16_NB>), grid, block, 0, stream, a); break;
-      default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-  }
   switch (ks32) {
-    case 1: hipLaunchKernelGGL((gmm_prefilter_kernel<1, 2>), grid, block, 0, stream, a); break;
-    case 2: hipLaunchKernelGGL((gmm_prefilter_kernel<2, 2>), grid, block, 0, stream, a); break;
-    case 3: hipLaunchKernelGGL((gmm_prefilter_kernel<3, 2>), grid, block, 0, stream, a); break;
+    case 1: hipLaunchKernelGGL((gmm_prefilter16_kernel<1, SR_P16_NB>), grid, block, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL((gmm_prefilter16_kernel<2, SR_P16_NB>), grid, block, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL((gmm_prefilter16_kernel<3, SR_P16_NB>), grid, block, 0, stream, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
 }
-int gmm_prefilter_frames_per_tile(int fp16) { return kPWaves * (fp16 ? SR_P16_NB : 2) * 16; }
+int gmm_prefilter_frames_per_tile() { return kPWaves * SR_P16_NB * 16; }
 
 // ---- kernel R ----------------------------------------------------------------------------------------------
 // State-stationary: a workgroup owns SPW (8, or 4 for wide features) consecutive states, whose FP64 parameters fill

@@ -53,18 +53,17 @@ struct GmmExactList {
 hipError_t launch_gmm_exact_listed(const GmmExactArgs& a, bool sum, const GmmExactList& L, uint32_t n_blocks, hipStream_t stream);
 int gmm_exact_frames_per_block();
 
-// ---- exact GMM scoring through a bf16 prefilter (gmm_prefilter.hip) ------------------------------------------------
+// ---- exact GMM scoring through an fp16 prefilter (gmm_prefilter.hip) ------------------------------------------------
 struct GmmPrefilterArgs {
   const float* feats;
   uint64_t n_frames;
   uint32_t dim;
-  const unsigned char* apack;   // [n_groups*8 blocks][KS32][hi/lo][64 lanes][8 bf16]
-  const float* grp_anorm;       // [n_groups*4][2] largest |a|_2 and |konst| over the densities of the state in that slot
+  const unsigned char* apack;   // [n_groups][8 blocks][KS32][64 lanes][8 fp16], scaled by a power of two
+  const float* grp_anorm;       // [n_groups*4][2] largest (scaled) |a|_2 and |konst| over the densities of the state in that slot
   const uint32_t* split_begin;  // [ny+1] group ranges
   uint32_t* mask;               // [group][frame][4 state slots] candidate densities of (frame, state)
   uint32_t nx, ny;
   uint32_t chunks;              // 1, 2 or 4 consecutive state slots (of 32 densities) make up one state
-  int fp16;                     // 1: single-product fp16 packing ([block][ks][lane][8 fp16]), 0: bf16 hi/lo
 };
 struct GmmRefineArgs {
   const float* featsT;          // [dim x n_frames_ld] transposed features
@@ -80,7 +79,7 @@ struct GmmRefineArgs {
   unsigned long long* n_refined;  // optional: += densities evaluated (profiling)
 };
 hipError_t launch_gmm_prefilter(const GmmPrefilterArgs& a, int ks32, hipStream_t stream);
-int gmm_prefilter_frames_per_tile(int fp16);
+int gmm_prefilter_frames_per_tile();
 int gmm_refine_slots(uint32_t max_dens);
 hipError_t launch_gmm_refine(const GmmRefineArgs& a, hipStream_t stream);
 hipError_t launch_transpose_feats(const float* feats, uint64_t n_frames, uint32_t dim, uint64_t ldT, float* out, hipStream_t stream);

@@ -94,9 +94,8 @@ struct sr_model {
   std::vector<uint32_t> group_first_block;  // host: [n_groups+1]
   DevBuf<uint32_t> split_begin;
   uint32_t split_ny = 0;
-  // bf16 prefilter + FP64 refinement (gmm_prefilter.hip); pf_ks32 == 0: model not eligible
+  // fp16 prefilter + FP64 refinement (gmm_prefilter.hip); pf_ks32 == 0: model not eligible
   int pf_ks32 = 0;
-  bool pf_fp16 = true;
   uint32_t pf_groups = 0, pf_ny = 0, max_dens = 0, pf_slots = 0, pf_chunks = 1, pf_pstates = 0;
   DevBuf<unsigned char> pf_apack;
   DevBuf<float> pf_anorm, featsT;
@@ -239,25 +238,11 @@ int pack_model(sr_model* m, const uint32_t* dens_off, const double* means, const
   return SR_OK;
 }
 
-// ---- model packing for the bf16 prefilter ---------------------------------------------------------------------
-// Groups of four states in natural order, each padded to 8 blocks of 16 rows (32 density slots per state); row r of
-// block j = density 4*j + (r & 3) of state slot (r >> 2).  Every coefficient is split into two bf16 terms
-// (round-to-nearest-even); fragment order [block][k-step of 32][hi, lo][lane][8]: lane l holds row l & 15,
-// k = 32*ks + 8*(l >> 4) + j -- the A operand of v_mfma_f32_16x16x32_bf16.
-uint16_t bf16_rne(float f) {
-  uint32_t u;
-  memcpy(&u, &f, 4);
-  if ((u & 0x7F800000u) == 0x7F800000u) return (uint16_t)((u >> 16) | ((u & 0xFFFFu) ? 0x40u : 0u));  // inf / NaN
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
-}
-float bf16_to_float(uint16_t h) {
-  const uint32_t u = (uint32_t)h << 16;
-  float f;
-  memcpy(&f, &u, 4);
-  return f;
-}
-
+// ---- model packing for the fp16 prefilter ---------------------------------------------------------------------
+// Groups of four (pseudo-)states in natural order, each padded to 8 blocks of 16 rows (32 density slots per state);
+// row r of block j = density 4*j + (r & 3) of state slot (r >> 2).  Coefficients are scaled by a power of two and
+// rounded once to fp16; fragment order [group][block][k-step of 32][lane][8]: lane l holds row l & 15,
+// k = 32*ks + 8*(l >> 4) + j -- the A operand of v_mfma_f32_16x16x32_f16.
 int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, const double* inv_vars,
                    const double* norm, const double* logw) {
   const uint32_t S = m->n_states, D = m->dim;
@@ -300,9 +285,6 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
   }
   const int KS = (int)((2 * D + 3 + 31) / 32);
   const uint32_t n_groups = (PS + 3) / 4;
-  const char* mode = getenv("SRGPU_PF_MODE");  // "bf16": three-product bf16 split (fewer candidates, 3x the MFMA work)
-  const bool fp16 = !(mode && strcmp(mode, "bf16") == 0);
-  m->pf_fp16 = fp16;
   const float finf = std::numeric_limits<float>::infinity();
   // per density: coefficients a = [1/(2 var); -mu/var] and the constant
   auto coeffs = [&](size_t c, std::vector<double>& arow) -> double {
@@ -316,9 +298,9 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
     return norm[c] - logw[c] + 0.5 * q2;
   };
   std::vector<double> arow(32 * (size_t)KS);
-  // fp16: one power-of-two scale for the whole model, the largest finite |coefficient| or |constant| -> [2^13, 2^14)
+  // one power-of-two scale for the whole model, the largest finite |coefficient| or |constant| -> [2^13, 2^14)
   double sA = 1.0;
-  if (fp16) {
+  {
     double big = 0.0;
     for (size_t c = 0; c < (size_t)m->n_dens; c++) {
       const double konst = coeffs(c, arow);
@@ -328,8 +310,7 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
     }
     if (big > 0.0) sA = std::ldexp(1.0, 13 - std::ilogb(big));
   }
-  const size_t parts = fp16 ? 1 : 2;
-  const size_t blk_bytes = (size_t)KS * parts * 1024;
+  const size_t blk_bytes = (size_t)KS * 1024;
   std::vector<uint16_t> ap((size_t)n_groups * 8 * blk_bytes / 2, 0);
   std::vector<float> anorm(8 * (size_t)n_groups, 0.0f);  // (sA |a|, sA |konst|) per state slot
   auto half_bits = [](double v) { const _Float16 h = (_Float16)(float)v; uint16_t u; memcpy(&u, &h, 2); return u; };
@@ -342,7 +323,7 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
         const bool real = ps < PS && i < ps_count(ps);
         const uint32_t st = ps < PS ? ps / Cs : 0;
         std::fill(arow.begin(), arow.end(), 0.0);
-        double konst = fp16 ? (double)finf : 3.0e38;  // padding slot: never below a real score, masked off again by the refinement
+        double konst = (double)finf;  // padding slot: never below a real score, masked off again by the refinement
         if (real) {
           konst = coeffs((size_t)dens_off[st] + 32u * (ps % Cs) + i, arow) * sA;
           double n2 = 0.0;
@@ -353,10 +334,10 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
           if (!(na <= anorm[2 * (4 * q + g)])) anorm[2 * (4 * q + g)] = na;
           if (!(nk <= anorm[2 * (4 * q + g) + 1])) anorm[2 * (4 * q + g) + 1] = nk;
         }
-        // konst = c1 + c2 + c3 (3 x 8 bits in bf16, 3 x 11 in fp16), multiplied by 1 in three spare k slots: exact products
+        // konst = c1 + c2 + c3 (3 x 11 bits), multiplied by 1 in three spare k slots: exact products
         double rest = konst;
         for (uint32_t t = 0; t < 3; t++) {
-          const double c = (real || t == 0) ? (fp16 ? half_value(half_bits(rest)) : (double)bf16_to_float(bf16_rne((float)rest))) : 0.0;
+          const double c = (real || t == 0) ? half_value(half_bits(rest)) : 0.0;
           arow[2 * D + t] = c;
           rest -= c;
         }
@@ -365,15 +346,7 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
             const uint32_t k = 32 * ks + kk;
             const double v = arow[k];
             const uint32_t lane = r + 16 * (kk >> 3), e = kk & 7;
-            if (fp16) {
-              ap[(b * blk_bytes) / 2 + (size_t)ks * 512 + (size_t)lane * 8 + e] = half_bits(v);
-            } else {
-              const uint16_t hi = bf16_rne((float)v);
-              const uint16_t lo = (real && k < 2 * D) ? bf16_rne((float)(v - (double)bf16_to_float(hi))) : (uint16_t)0;
-              const size_t base = (b * blk_bytes) / 2 + (size_t)ks * 1024 + (size_t)lane * 8 + e;
-              ap[base] = hi;
-              ap[base + 512] = lo;
-            }
+            ap[(b * blk_bytes) / 2 + (size_t)ks * 512 + (size_t)lane * 8 + e] = half_bits(v);
           }
       }
     }
@@ -479,7 +452,7 @@ int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm
     HIP_TRY(launch_gmm_mfma(a, m->ksteps, !m->max_approx, m->s_gmm));
     if ((rc = prof_end(m, m->s_gmm, &ep))) return rc;
   } else if (gmm_kernel == SR_GMM_PREFILTER && m->pf_ks32 > 0) {
-    const uint32_t tile = gmm_prefilter_frames_per_tile(m->pf_fp16);
+    const uint32_t tile = gmm_prefilter_frames_per_tile();
     const uint32_t nx = (uint32_t)((n_frames + tile - 1) / tile);
     int rc = set_prefilter_splits(m, nx);
     if (rc) return rc;
@@ -489,7 +462,7 @@ int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm
     GmmPrefilterArgs pa{};
     pa.feats = d_feats; pa.n_frames = n_frames; pa.dim = m->dim;
     pa.apack = m->pf_apack.p; pa.grp_anorm = m->pf_anorm.p; pa.split_begin = m->pf_split.p;
-    pa.mask = m->pf_mask.p; pa.nx = nx; pa.ny = m->pf_ny; pa.fp16 = m->pf_fp16; pa.chunks = m->pf_chunks;
+    pa.mask = m->pf_mask.p; pa.nx = nx; pa.ny = m->pf_ny; pa.chunks = m->pf_chunks;
     GmmRefineArgs ra{};
     ra.featsT = m->featsT.p; ra.n_frames = n_frames; ra.n_frames_ld = ldT; ra.dim = m->dim; ra.n_pstates = m->pf_pstates; ra.chunks = m->pf_chunks;
     ra.n_dens_ps = m->pf_ndens.p; ra.rows = m->pf_rows.p; ra.n_slots = m->pf_slots;
