@@ -187,6 +187,10 @@ SR_API int sr_bigram_destroy(sr_bigram* b);
 SR_API int sr_recognize_bigram_corpus(sr_model* m, sr_corpus* c, sr_bigram* b, const sr_bigram_params* p,
                                       uint32_t* out_word, float* out_score, uint32_t* out_time, uint64_t* out_off);
 
+/* Diagnostic: does the fp16 matrix pipe keep subnormal inputs on this device (an assumption of SR_GMM_PREFILTER's
+ * error bound; when it does not hold, models are scored by SR_GMM_EXACT's kernel instead)? */
+SR_API int sr_probe_fp16_denormals(int device, int* preserved);
+
 /* ---- measurement --------------------------------------------------------------------------------
  * When enabled, every kernel launch of this model handle is bracketed by HIP events on the
  * launch stream; sr_profile_read() synchronises and returns accumulated device times. */

@@ -204,6 +204,34 @@ __global__ __launch_bounds__(kPWaves * 64, (NB <= 2 ? 3 : 2)) void gmm_prefilter
   }
 }
 
+// The error bound above counts fp16 subnormals as representable (spacing 2^-24).  hipcc's default kernel mode keeps
+// them (float_denorm_mode_16_64 = preserve) and MFMA A/B inputs honour that mode; this probe checks it on the device
+// the model is created on: 2^-20 (subnormal in fp16) x 2^10 must come out as 2^-10, not 0.
+__global__ void fp16_denormal_probe_kernel(float* out) {
+  const int lane = threadIdx.x;
+  f16x8 a = {0, 0, 0, 0, 0, 0, 0, 0}, b = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (lane < 16) { a[0] = (_Float16)9.5367431640625e-7f; b[0] = (_Float16)1024.0f; }  // k = 0 of every row / column
+  v4f acc = {0.f, 0.f, 0.f, 0.f};
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+  out[lane] = acc[0];
+}
+
+hipError_t probe_fp16_denormals(hipStream_t stream, bool* preserved) {
+  float* d = nullptr;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d), 64 * sizeof(float));
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(fp16_denormal_probe_kernel, dim3(1), dim3(64), 0, stream, d);
+  float h[64];
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e == hipSuccess) e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return e;
+  *preserved = true;
+  for (int i = 0; i < 64; i++) *preserved = *preserved && h[i] == 9.765625e-4f;
+  return hipSuccess;
+}
+
 hipError_t launch_gmm_prefilter(const GmmPrefilterArgs& a, int ks32, hipStream_t stream) {
   const dim3 grid(a.nx * a.ny), block(kPWaves * 64);
   switch (ks32) {

@@ -251,6 +251,11 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
   m->max_dens = std::max(1u, mx);
   m->pf_ks32 = 0;
   if (!m->max_approx || mx > 128 || 2 * D + 3 > 96) return SR_OK;  // not eligible: callers get the exact kernel
+  {
+    bool preserved = false;
+    HIP_TRY(probe_fp16_denormals(m->s_gmm, &preserved));
+    if (!preserved) return SR_OK;  // the bound of gmm_prefilter.hip does not hold with flushed subnormals: exact kernel
+  }
   // A mixture of more than 32 densities is cut into Cs = 2 or 4 chunks of 32: the kernels see S*Cs pseudo-states
   // (ps = st*Cs + chunk), the prefilter takes the minimum across a state's chunks, the refinement folds them.
   const uint32_t Cs = mx <= 32 ? 1u : mx <= 64 ? 2u : 4u;
@@ -1275,6 +1280,15 @@ int sr_accumulate_corpus(sr_model* m, sr_corpus* c, const uint16_t* states, int 
   HIP_TRY(hipMemcpy(mean_w, c->w_mean.p, sizeof(double) * m->n_mean, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(var_acc, c->acc_var.p, sizeof(double) * (size_t)m->n_var * D, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(var_w, c->w_var.p, sizeof(double) * m->n_var, hipMemcpyDeviceToHost));
+  return SR_OK;
+}
+
+int sr_probe_fp16_denormals(int device, int* preserved) {
+  if (!preserved) return fail(SR_EINVAL, "preserved is null");
+  HIP_TRY(hipSetDevice(device));
+  bool ok = false;
+  HIP_TRY(probe_fp16_denormals(nullptr, &ok));
+  *preserved = ok ? 1 : 0;
   return SR_OK;
 }
 

@@ -492,3 +492,13 @@ def test_prefilter_full_size_matches_exact_kernel(tmp_path):
         got = m.score_frames(feats, capi.GMM_PREFILTER)
         exact = m.score_frames(feats, capi.GMM_EXACT)
     assert np.array_equal(got.view(np.uint64), exact.view(np.uint64))
+
+
+def test_fp16_matrix_pipe_keeps_subnormals():
+    """An assumption of the prefilter's error bound (gmm_prefilter.hip): fp16 subnormal inputs are not flushed.  If this
+    ever fails the library falls back to the exact kernel by itself; the test makes the change visible."""
+    import ctypes as C
+
+    ok = C.c_int(0)
+    assert capi.lib().sr_probe_fp16_denormals(0, C.byref(ok)) == 0
+    assert ok.value == 1
