@@ -482,12 +482,14 @@ def test_prefilter_scores_are_bit_identical(tmp_path, oracle_lib, seed, S, M, D,
 
 
 def test_prefilter_full_size_matches_exact_kernel(tmp_path):
-    """4000 states x 32 densities (bench model): 3000 frames through both exact paths, compared bit for bit."""
+    """4000 states x 32 densities (bench model): 12 000 frames (48 M (frame, state) pairs, 1.5 G density scores
+    behind them) through both exact paths, compared bit for bit -- a miss of the true arg-min by the fp16 stage's
+    error bound would show up here."""
     lex = synth.make_lexicon(1333, 3, 1)
     spec = synth.make_mixset(lex.n_states, 32, 39, seed=5)
     mp = str(tmp_path / "big.mix")
     synth.write_mixset(mp, spec)
-    feats, _ = synth.make_batch(10, 200, 400, 39, seed=11)
+    feats, _ = synth.make_batch(40, 200, 400, 39, seed=11)
     with capi.Model.from_mixset(mp, 39) as m:
         got = m.score_frames(feats, capi.GMM_PREFILTER)
         exact = m.score_frames(feats, capi.GMM_EXACT)
