@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/srgpu.h"
@@ -126,9 +127,13 @@ static void finalize_mixset(const Mixset& ms, int pooling, MixsetTables* out) {
     for (size_t d = 0; d < D; d++) acc = acc + log(v[d]);
     nrm[vi] = acc / 2;
   };
-  double total = 0.0;
-  std::vector<double> pooled(D);
-  for (auto& mix : mixtures) {
+  // One mixture at a time, as the reference does.  When no mean or variance row is shared between mixtures (the
+  // usual case) the mixtures are independent and are spread over host threads -- every value is computed by the same
+  // operations in the same order, so the result does not depend on the thread count; shared rows keep the
+  // reference's sequential order (the last writer wins there).
+  std::vector<double> mix_totals(mixtures.size(), 0.0);
+  auto do_mixture = [&](size_t mi, std::vector<double>& pooled) {
+    const std::vector<Density>& mix = mixtures[mi];
     double mix_total = 0.0;
     for (const Density& dn : mix) {
       mix_total += mean_acc.weight[dn.mean];
@@ -143,8 +148,37 @@ static void finalize_mixset(const Mixset& ms, int pooling, MixsetTables* out) {
       for (size_t d = 0; d < D; d++) pooled[d] = pooled[d] / mix_total;
       variance(mix[0].var, pooled.data());
     }
-    total += mix_total;
+    mix_totals[mi] = mix_total;
+  };
+  bool independent = true;
+  {
+    std::vector<uint32_t> mean_owner(mean_acc.n, 0xFFFFFFFFu), var_owner(var_acc.n, 0xFFFFFFFFu);
+    for (size_t mi = 0; mi < mixtures.size() && independent; mi++)
+      for (const Density& dn : mixtures[mi]) {
+        if ((mean_owner[dn.mean] != 0xFFFFFFFFu && mean_owner[dn.mean] != mi) || (var_owner[dn.var] != 0xFFFFFFFFu && var_owner[dn.var] != mi)) {
+          independent = false;
+          break;
+        }
+        mean_owner[dn.mean] = var_owner[dn.var] = (uint32_t)mi;
+      }
   }
+  const unsigned hw = std::thread::hardware_concurrency();
+  const size_t n_threads = (independent && mixtures.size() >= 256) ? std::max(1u, std::min(16u, hw ? hw : 1u)) : 1;
+  if (n_threads > 1) {
+    std::vector<std::thread> pool;
+    for (size_t t = 0; t < n_threads; t++)
+      pool.emplace_back([&, t]() {
+        std::vector<double> pooled(D);
+        for (size_t mi = mixtures.size() * t / n_threads; mi < mixtures.size() * (t + 1) / n_threads; mi++) do_mixture(mi, pooled);
+      });
+    for (auto& th : pool) th.join();
+  } else {
+    std::vector<double> pooled(D);
+    for (size_t mi = 0; mi < mixtures.size(); mi++) do_mixture(mi, pooled);
+  }
+  double total = 0.0;
+  for (double mt : mix_totals) total += mt;  // in mixture order, like the reference's running sum
+  std::vector<double> pooled(D);
   if (pooling == SRHOST_POOL_GLOBAL) {
     std::fill(pooled.begin(), pooled.end(), 0.0);
     for (auto& mix : mixtures)
