@@ -203,6 +203,8 @@ def test_restatement_ties_and_merge_quirk(tmp_path, oracle_lib):
     (14, 6, 1, 80.0, FLT_MAX, 1),
     (15, 40, 3, 120.0, 20.0, 1),
     (16, 300, 3, 150.0, 12.0, 1),     # more words than one pass of the recombination staging buffer
+    (17, 1100, 2, 90.0, 8.0, 1),      # more words than threads: two words per thread in the recombination
+    (18, 2200, 1, 60.0, 6.0, 1),      # four words per thread, one-state words
 ])
 def test_gpu_bigram_matches_restatement(tmp_path, oracle_lib, seed, W, spw, acp, lmp, sil_states):
     from speechrecognition_amd import capi
