@@ -33,7 +33,7 @@ namespace srgpu {
 
 static constexpr int kBgThreads = 1024;
 static constexpr int kBgWaves = kBgThreads / 64;
-static constexpr int kBgStage = 256;  // word ends staged per pass of the recombination loop
+static constexpr int kBgStage = 256;  // word ends staged per pass of the recombination loop (more for big lexica, see `stage`)
 static constexpr float kFltMax = 3.402823466e+38f;
 // flags on a word end of the merged list (see step 6): the same word end also sits LATER in the list / sat EARLIER
 static constexpr uint32_t kShadowed = 0x80000000u, kRepeat = 0x40000000u, kSlotMask = 0x3FFFFFFFu;
@@ -138,8 +138,16 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
     for (uint32_t e = tid; e < n_we; e += kBgThreads)
       lu = fminf(lu, we_score[cur][e] + a.lm_rowmax[map_copy(we_slot[cur][e] & kSlotMask)]);
     const float U = wg_min(lu, red_tmp);
-    for (uint32_t e0 = 0; e0 < n_we; e0 += kBgStage) {
-      const uint32_t ne_in = (n_we - e0 < (uint32_t)kBgStage) ? n_we - e0 : kBgStage;
+    // staging buffer: the dedicated 256 entries, or -- for a big lexicon -- the idle half of the active-list double
+    // buffer (it is rewritten from scratch in step 4), up to one entry per thread: fewer passes and barriers
+    uint32_t* stg = stage;
+    uint32_t stg_cap = kBgStage;
+    if ((W2 * 2u) / 12u > (uint32_t)kBgStage) {
+      stg = reinterpret_cast<uint32_t*>(L[lcur ^ 1]);
+      stg_cap = (W2 * 2u) / 12u < (uint32_t)kBgThreads ? (W2 * 2u) / 12u : (uint32_t)kBgThreads;
+    }
+    for (uint32_t e0 = 0; e0 < n_we; e0 += stg_cap) {
+      const uint32_t ne_in = (n_we - e0 < stg_cap) ? n_we - e0 : stg_cap;
       __syncthreads();
       // stage the surviving word ends of this chunk, in list order (ballot prefix within the chunk's four waves)
       bool keep = false;
@@ -161,21 +169,21 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
         }
       }
       const uint64_t bal = __ballot(keep);
-      if (tid < kBgStage && (tid & 63) == 0) scan_tmp[tid >> 6] = (uint32_t)__popcll(bal);
+      if ((tid & 63) == 0) scan_tmp[tid >> 6] = (uint32_t)__popcll(bal);
       __syncthreads();
       uint32_t ne = 0;
       {
         uint32_t before = 0;
-        for (int wv = 0; wv < kBgStage / 64; wv++) {
+        for (int wv = 0; wv < kBgWaves; wv++) {
           const uint32_t c = scan_tmp[wv];
           if (wv < (int)(tid >> 6)) before += c;
           ne += c;
         }
         if (keep) {
           const uint32_t pos = before + (uint32_t)__popcll(bal & ((1ull << (tid & 63)) - 1ull));
-          stage[3 * pos] = h;
-          stage[3 * pos + 1] = __float_as_uint(sc_e);
-          stage[3 * pos + 2] = bp_e;
+          stg[3 * pos] = h;
+          stg[3 * pos + 1] = __float_as_uint(sc_e);
+          stg[3 * pos + 2] = bp_e;
         }
       }
       __syncthreads();
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
           const uint32_t ej = (e + j < ne) ? e + j : e;
-          const float* row = a.lmT + (uint64_t)stage[3 * ej] * W;
+          const float* row = a.lmT + (uint64_t)stg[3 * ej] * W;
 #pragma unroll
           for (int k = 0; k < KW; k++) {
             const uint32_t w = tid + k * kBgThreads;
@@ -196,8 +204,8 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
           if (e + j < ne) {  // workgroup-uniform
-            const float sc = __uint_as_float(stage[3 * (e + j) + 1]);
-            const uint32_t bp = stage[3 * (e + j) + 2];
+            const float sc = __uint_as_float(stg[3 * (e + j) + 1]);
+            const uint32_t bp = stg[3 * (e + j) + 2];
 #pragma unroll
             for (int k = 0; k < KW; k++) {
               const float ns = sc + v[j][k];
