@@ -78,6 +78,28 @@ __device__ inline void wave_min_idx_dpp(double& v, uint32_t& idx) {
   idx = (uint32_t)__builtin_amdgcn_readlane((int)idx, 63);
 }
 
+// minimum over a row of 16 lanes, in every lane of the row (the cross-wave stage: each row holds all <= 16 partials)
+__device__ inline double row_min_dpp(double v) {
+  double o;
+  o = dpp_d<0xB1, 0xF>(v); v = o < v ? o : v;
+  o = dpp_d<0x4E, 0xF>(v); v = o < v ? o : v;
+  o = dpp_d<0x141, 0xF>(v); v = o < v ? o : v;
+  o = dpp_d<0x140, 0xF>(v); v = o < v ? o : v;
+  return v;
+}
+__device__ inline void row_min_idx_dpp(double& v, uint32_t& idx) {
+#define SR_STEP(CTRL, MASK)                                               \
+  {                                                                       \
+    const double ov = dpp_d<CTRL, MASK>(v);                               \
+    const uint32_t oi = (uint32_t)dpp_i<CTRL, MASK>((int)idx);            \
+    const bool take = ov < v || (ov == v && oi < idx);                    \
+    v = take ? ov : v;                                                    \
+    idx = take ? oi : idx;                                                \
+  }
+  SR_STEP(0xB1, 0xF) SR_STEP(0x4E, 0xF) SR_STEP(0x141, 0xF) SR_STEP(0x140, 0xF)
+#undef SR_STEP
+}
+
 // chunk type word (one per 64 slots): kind | flags
 static constexpr uint32_t kKindMask = 7u;
 static constexpr uint32_t kE0 = 0, kE0S = 1, kE1 = 2, kE1E = 3, kM = 4, kME = 5, kPad = 6;
@@ -106,17 +128,28 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
   const double tl = a.net.tdp_loop, tf = a.net.tdp_forward, ts = a.net.tdp_skip;
   const double wp_word = a.word_penalty, thr = a.am_threshold;
 
+  // Slot of (thread, i).  Many utterances in flight (throughput): a wave owns SPT consecutive 64-slot chunks, so only the
+  // waves that hold word-end kinds pay for the word-end reduction.  Few utterances (latency): chunks are dealt round-robin
+  // so that every wave carries the same mix of kinds and none of them is the straggler at the frame barrier.
+  const bool dealt = a.n_utts < 128;
+  auto slot_of = [&](int i) -> uint32_t { return dealt ? tid + (uint32_t)i * NT : (wave * SPT + (uint32_t)i) * 64 + lane; };
   // ---- static per-slot constants ------------------------------------------------------------------------
   uint32_t st[SPT], pr[SPT], og[SPT], ty[SPT];
 #pragma unroll
   for (int i = 0; i < SPT; i++) {
-    const uint32_t p = tid + i * NT;
+    const uint32_t p = slot_of(i);
     const bool in = p < net.n_slots;
     st[i] = in ? net.state[p] : 0u;      // padding slots read state 0: a valid address, value unused
     pr[i] = in ? net.pred[p] : (p | (p << 16));
     og[i] = in ? net.orig[p] : 0xFFFFFFFFu;
     ty[i] = __builtin_amdgcn_readfirstlane(in ? net.chunk_type[p >> 6] : kPad);  // one type per 64-slot chunk
     sc[p] = kInfF; bk[p] = 0;
+  }
+  bool wave_has_we = false;  // wave-uniform: does any of this wave's chunks hold word-end slots?
+#pragma unroll
+  for (int i = 0; i < SPT; i++) {
+    const uint32_t kind = ty[i] & kKindMask;
+    wave_has_we |= (kind == kE0S || kind == kE1E || kind == kME);
   }
   if (tid < 8) e_first[tid] = 0xFFFFFFFFu;
   if (tid == 8) *bail = 0;
@@ -131,7 +164,7 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
   double am_n[SPT];  // emission gathers one frame ahead: frame t+1's costs are issued at the top of frame t
 #pragma unroll
   for (int i = 0; i < SPT; i++) {
-    const uint32_t p = tid + i * NT;
+    const uint32_t p = slot_of(i);
     am_n[i] = T > 0 ? row0[st[i]] : 0.0;
     am_l[p] = am_n[i];
   }
@@ -159,7 +192,7 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
     bool neg = false;
 #pragma unroll
     for (int i = 0; i < SPT; i++) {
-      const uint32_t p = tid + i * NT;
+      const uint32_t p = slot_of(i);
       const uint32_t type = ty[i], kind = type & kKindMask;
       nv[i] = kInfF; nb[i] = 0;
       if (kind == kPad) continue;  // wave-uniform
@@ -221,7 +254,7 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
     SR_STAMP(1);
     // ---- B ----------------------------------------------------------------------------------------------
     my_best = wave_min_dpp(my_best);
-    wave_min_idx_dpp(my_we, my_we_idx);
+    if (wave_has_we) wave_min_idx_dpp(my_we, my_we_idx);  // (other waves keep +inf / no index)
     if (lane == 0) { red_best[wave] = my_best; red_we[wave] = my_we; red_idx[wave] = my_we_idx; }
     SR_STAMP(2);
     __syncthreads();
@@ -232,9 +265,10 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
     }
     double best = red_best[lane & (NW - 1)], we = red_we[lane & (NW - 1)];
     uint32_t we_idx = red_idx[lane & (NW - 1)];
-    if (NW > 1) {
-      best = wave_min_dpp(best);
-      wave_min_idx_dpp(we, we_idx);
+    if (NW > 1) {  // NW <= 16 partials, replicated in every row of 16 lanes: a row-level reduction is enough
+      static_assert(NW <= 16, "one row of 16 lanes holds all per-wave partials");
+      best = row_min_dpp(best);
+      row_min_idx_dpp(we, we_idx);
     }
 
     // ---- C ----------------------------------------------------------------------------------------------
@@ -244,7 +278,7 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
     const double near = m_we + (fabs(m_we) + fabs(wp_word) + fabs(tf) + fabs(ts) + 1.0) * 1e-9;
 #pragma unroll
     for (int i = 0; i < SPT; i++) {
-      const uint32_t p = tid + i * NT;
+      const uint32_t p = slot_of(i);
       const uint32_t kind = ty[i] & kKindMask;
       double v = nv[i];
       if (v > limit) v = kInfF;  // :194-196

@@ -504,3 +504,37 @@ def test_fp16_matrix_pipe_keeps_subnormals():
     ok = C.c_int(0)
     assert capi.lib().sr_probe_fp16_denormals(0, C.byref(ok)) == 0
     assert ok.value == 1
+
+
+@pytest.mark.parametrize("W,beam", [(60, 60.0), (700, 150.0)])
+def test_many_utterances_use_the_throughput_slot_layout(tmp_path, oracle_lib, W, beam):
+    """With >= 128 utterances in a launch the decoder gives every wave consecutive slot chunks (only word-end waves run
+    the word-end reduction) instead of dealing chunks round-robin: same words, utterance for utterance."""
+    lex, spec, mp = _random_setup(tmp_path, 700 + W, W, 3, 1, 2, 12)
+    o = oracle_lib.Oracle(mp, 12, lex, am_threshold=beam)
+    rng = np.random.default_rng(W)
+    lens = rng.integers(12, 30, size=160)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    feats = rng.standard_normal((int(off[-1]), 12)).astype(np.float32)
+    for u in range(0, 160, 7):  # some utterances drawn from the model, so that the beam prunes
+        x = synth.sample_utterance(spec, lex, rng.integers(1, lex.n_words, size=2), seed=u)[: lens[u]]
+        feats[int(off[u]):int(off[u]) + len(x)] = x
+    word_off, automaton, sil_state = lex.flatten()
+    with capi.Model.from_mixset(mp, 12) as m:
+        lexh = m.lexicon(word_off, automaton, lex.silence_idx, (3.0, 0.0, 30.0), sil_state)
+        corpus = m.upload(feats, off)
+        words, woff, (tbs, tbw, tbb) = corpus.recognize(lexh, beam, 10.0, capi.GMM_PREFILTER, traceback=True)
+        few = m.upload(feats[: int(off[5])], off[:6])  # the same first utterances through the round-robin layout
+        wf, of = few.recognize(lexh, beam, 10.0, capi.GMM_PREFILTER)
+        assert np.array_equal(wf, words[: int(woff[5])]) and np.array_equal(of, woff[:6])
+        few.close()
+        for u in range(160):
+            x = feats[int(off[u]):int(off[u + 1])]
+            w, (os_, ow, ob) = o.decode(x, traceback=True)
+            assert np.array_equal(w, words[int(woff[u]):int(woff[u + 1])]), u
+            a = int(off[u]) + u
+            assert np.array_equal(tbw[a:a + len(x) + 1], ow) and np.array_equal(tbb[a:a + len(x) + 1], ob)
+            assert np.array_equal(tbs[a:a + len(x) + 1].view(np.uint64), os_.view(np.uint64))
+        corpus.close()
+        lexh.close()
+    o.close()
