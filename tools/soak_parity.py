@@ -1,0 +1,90 @@
+"""Randomised soak of the GPU path against the CPU oracle: random lexica / mixtures / dims / beams / utterance sets,
+scores (prefilter, exact) bit-identical, words + tracebacks + alignments identical, bigram search identical.
+usage: python tools/soak_parity.py [n_cases] [seed]"""
+import os, sys, tempfile, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from speechrecognition_amd import capi, synth
+from oracle import pyoracle
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+tmp = tempfile.mkdtemp()
+t_start = time.time()
+for case in range(n_cases):
+    rng = np.random.default_rng(seed0 * 100003 + case)
+    W = int(rng.choice([2, 5, 17, 60, 300]))
+    spw = int(rng.integers(1, 5))
+    reps = int(rng.integers(1, 3))
+    if spw * reps < 2:
+        reps = 2  # (the decoder wants a word with two or more positions: sr_lexicon_create's documented limit)
+    D = int(rng.choice([4, 12, 25, 39, 46, 50]))
+    Mhi = int(rng.choice([1, 3, 8, 33, 70]))
+    lex = synth.make_lexicon(W, spw, reps)
+    nm = rng.integers(1, Mhi + 1, size=lex.n_states)
+    spec = synth.make_mixset(lex.n_states, nm, D, seed=case, var_floor=float(rng.choice([0.5, 1e-3])))
+    mp = os.path.join(tmp, "m.mix")
+    synth.write_mixset(mp, spec)
+    beam = float(rng.choice([15.0, 60.0, 200.0, 1e9]))
+    n_utts = int(rng.choice([1, 3, 9, 140]))
+    lens = rng.integers(1, 40, size=n_utts)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    feats = (float(rng.choice([1.0, 3.0])) * rng.standard_normal((int(off[-1]), D))).astype(np.float32)
+    for u in range(0, n_utts, 3):
+        x = synth.sample_utterance(spec, lex, rng.integers(1, lex.n_words, size=2), seed=case + u)[: lens[u]]
+        feats[int(off[u]):int(off[u]) + len(x)] = x
+    word_off, automaton, sil = lex.flatten()
+    o = pyoracle.Oracle(mp, D, lex, am_threshold=beam)
+    want = o.score_matrix(feats)
+    tag = f"case {case}: W={W} spw={spw} reps={reps} D={D} M<={Mhi} beam={beam} utts={n_utts}"
+    with capi.Model.from_mixset(mp, D) as m:
+        corpus = m.upload(feats, off)
+        for k in (capi.GMM_PREFILTER, capi.GMM_EXACT):
+            got = corpus.score(k)
+            assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (tag, "scores", k)
+        lexh = m.lexicon(word_off, automaton, lex.silence_idx, (3.0, 0.0, 30.0), sil)
+        words, woff, (tbs, tbw, tbb) = corpus.recognize(lexh, beam, 10.0, capi.GMM_PREFILTER, traceback=True)
+        auts, ok_al = [], True
+        for u in range(n_utts):
+            x = feats[int(off[u]):int(off[u + 1])]
+            w, (os_, ow, ob) = o.decode(x, traceback=True)
+            assert np.array_equal(w, words[int(woff[u]):int(woff[u + 1])]), (tag, "words", u)
+            a = int(off[u]) + u
+            assert np.array_equal(tbw[a:a + len(x) + 1], ow) and np.array_equal(tbb[a:a + len(x) + 1], ob), (tag, "tb", u)
+            assert np.array_equal(tbs[a:a + len(x) + 1].view(np.uint64), os_.view(np.uint64)), (tag, "tb score", u)
+            ws = rng.integers(1, lex.n_words, size=2) if lex.n_words > 1 else []
+            aut = [sil]
+            for w_ in ws:
+                aut += list(automaton[word_off[w_]:word_off[w_ + 1]]) + [sil]
+            if len(aut) > len(x):
+                aut = aut[: len(x)]
+            auts.append(np.asarray(aut, np.uint16))
+        st, cost = corpus.align(auts, (3.0, 0.0, 30.0), sil)
+        stp, costp = corpus.align(auts, (3.0, 0.0, 30.0), sil, pruning_threshold=50.0)
+        for u in range(n_utts):
+            x = feats[int(off[u]):int(off[u + 1])]
+            s_, c_ = o.align_full(x, auts[u])
+            assert np.array_equal(st[int(off[u]):int(off[u + 1])], s_) and cost[u] == c_, (tag, "align", u)
+            s_, c_ = o.align_pruned(x, auts[u], 50.0)
+            assert np.array_equal(stp[int(off[u]):int(off[u + 1])], s_) and costp[u] == c_, (tag, "align pruned", u)
+        # bigram search on the same model (the automaton positions are the lexicon's mixtures)
+        nW = lex.n_words
+        if nW <= 400:
+            lm = (-np.log(rng.dirichlet(np.ones(nW), size=nW))).T.astype(np.float32).copy()
+            tdp = np.array([[3.0, 0.0, 30.0, float(rng.choice([0.0, 5.0]))], [1.0, 0.0, 40.0, 2.0]], np.float32)
+            acp = float(rng.choice([30.0, 120.0, pyoracle.FLT_MAX]))
+            lmp = float(rng.choice([5.0, 25.0, pyoracle.FLT_MAX]))
+            bg = m.bigram(word_off, automaton, lex.silence_idx, lm, tdp)
+            gw, gs, gt, goff = corpus.recognize_bigram(bg, acp, lmp)
+            for u in range(n_utts):
+                x = feats[int(off[u]):int(off[u + 1])]
+                w, s_, t_ = pyoracle.bigram_decode(want[int(off[u]):int(off[u + 1])], word_off, automaton, lex.silence_idx, lm, tdp, acp, lmp)
+                a, b = int(goff[u]), int(goff[u + 1])
+                assert np.array_equal(gw[a:b], w) and np.array_equal(gt[a:b], t_), (tag, "bigram", u)
+                assert np.array_equal(gs[a:b].view(np.uint32), s_.view(np.uint32)), (tag, "bigram score", u)
+            bg.close()
+        lexh.close()
+        corpus.close()
+    o.close()
+    print(f"ok {tag}  [{time.time() - t_start:.0f} s]", flush=True)
+print("soak passed:", n_cases, "cases")
