@@ -1,0 +1,34 @@
+"""PCIe-inclusive rate at the boundary that hands over host buffers: upload (sr_corpus_upload) + recognise + destroy per
+step, against the resident-features rate bench.py reports.  usage: python tools/time_batch_boundary.py"""
+import os, sys, tempfile, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from speechrecognition_amd import capi, synth
+
+lex = synth.make_lexicon(1333, 3, 1)
+spec = synth.make_mixset(lex.n_states, 32, 39, seed=23)
+mp = os.path.join(tempfile.mkdtemp(), "m.mix")
+synth.write_mixset(mp, spec)
+feats, off = synth.make_batch(1000, 200, 400, 39, seed=7)
+word_off, automaton, sil = lex.flatten()
+with capi.Model.from_mixset(mp, 39) as m:
+    lexh = m.lexicon(word_off, automaton, lex.silence_idx, (3.0, 0.0, 30.0), sil)
+    def host_step():
+        c = m.upload(feats, off)
+        r = c.recognize(lexh, 200.0, 10.0)
+        c.close()
+        return r
+    host_step()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        host_step()
+    t_host = (time.perf_counter() - t0) / 3
+    c = m.upload(feats, off)
+    c.recognize(lexh, 200.0, 10.0)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        c.recognize(lexh, 200.0, 10.0)
+    t_res = (time.perf_counter() - t0) / 3
+    c.close(); lexh.close()
+print(f"resident features: {t_res*1e3:.1f} ms/step = {len(feats)/t_res:,.0f} frames/s; "
+      f"host buffers (47 MB pageable H2D + alloc/free per step): {t_host*1e3:.1f} ms/step = {len(feats)/t_host:,.0f} frames/s")
