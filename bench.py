@@ -163,7 +163,7 @@ def main():
             },
             "roofline": gmm_roofline(args, prof, n_frames, D, S),
             "search": {
-                "kernel": "decode_kernel",
+                "kernel": "decode_fast_kernel",
                 "bound": "hbm",
                 "ms_per_step": prof["search_ms"] / args.steps,
                 "achieved_GBps": prof["search_bytes"] / (prof["search_ms"] * 1e-3) / 1e9 if prof["search_ms"] > 0 else 0.0,
