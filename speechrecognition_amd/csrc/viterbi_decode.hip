@@ -23,9 +23,10 @@
 //   C  prune `score > best + am_threshold` (:194), record traceback[t] = first minimal surviving
 //      word end (:199-205), publish the word-end minimum and first-index per class for frame t+1.
 //
-// HBM traffic per frame is the emission row gather (8 B per slot) plus one 12-byte traceback
-// entry; everything else stays in LDS/registers: the kernel is bound by HBM/L2 latency of the
-// score rows and two workgroup barriers per frame.
+// This file holds the GENERAL kernel: slots in reference order, every per-slot decision taken per lane, the
+// sequential boundary replay inline.  Production launches run viterbi_fast.hip's type-sorted kernel first (same
+// results, ~5x fewer instructions per frame) and this one, as decode_kernel<.., REPLAY = true>, only for the
+// utterances the fast kernel hands back (out_flags bit 1: a negative emission cost was seen).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
