@@ -183,21 +183,32 @@ __global__ __launch_bounds__(kPWaves * 64, (NB <= 2 ? 3 : 2)) void gmm_prefilter
     for (int nb = 0; nb < NB; nb++) {
       // v_min3_f32 directly: the hardware minimum already drops (quiet) NaNs; fminf() would canonicalise every operand
       // first (one v_max_f32 each).  Should a NaN survive, the limit is NaN and every density stays a candidate.
+      // (one asm statement per two blocks: the compiler pads every asm statement with an s_nop)
       float amin = __builtin_huge_valf();
 #pragma unroll
-      for (int j = 0; j < kGroupBlocks; j++) {
-        asm("v_min3_f32 %0, %0, %1, %2" : "+v"(amin) : "v"(ap[nb][j][0]), "v"(ap[nb][j][1]));
-        asm("v_min3_f32 %0, %0, %1, %2" : "+v"(amin) : "v"(ap[nb][j][2]), "v"(ap[nb][j][3]));
-      }
+      for (int j = 0; j < kGroupBlocks; j += 2)
+        asm("v_min3_f32 %0, %0, %1, %2\n\tv_min3_f32 %0, %0, %3, %4\n\tv_min3_f32 %0, %0, %5, %6\n\tv_min3_f32 %0, %0, %7, %8"
+            : "+v"(amin)
+            : "v"(ap[nb][j][0]), "v"(ap[nb][j][1]), "v"(ap[nb][j][2]), "v"(ap[nb][j][3]), "v"(ap[nb][j + 1][0]),
+              "v"(ap[nb][j + 1][1]), "v"(ap[nb][j + 1][2]), "v"(ap[nb][j + 1][3]));
       if (a.chunks >= 2) { const float o = __shfl_xor(amin, 16); asm("v_min_f32 %0, %0, %1" : "+v"(amin) : "v"(o)); }  // the other chunk(s) of the state
       if (a.chunks >= 4) { const float o = __shfl_xor(amin, 32); asm("v_min_f32 %0, %0, %1" : "+v"(amin) : "v"(o)); }
       const float limit = amin + 2.0f * (kKappa16 * nk.x * bnorm[nb] + kKonst16 * nk.y + kAbs16 * (bnorm[nb] + nk.x));
       uint32_t mask = 0;
 #pragma unroll
-      for (int j = kGroupBlocks - 1; j >= 0; j--)
-#pragma unroll
-        for (int i = 3; i >= 0; i--)
-          asm("v_cmp_ngt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(ap[nb][j][i]), "v"(limit) : "vcc");
+      for (int j = kGroupBlocks - 1; j >= 1; j -= 2)  // densities in descending order, two blocks per asm statement
+        asm("v_cmp_ngt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+            "v_cmp_ngt_f32 vcc, %3, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+            "v_cmp_ngt_f32 vcc, %4, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+            "v_cmp_ngt_f32 vcc, %5, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+            "v_cmp_ngt_f32 vcc, %6, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+            "v_cmp_ngt_f32 vcc, %7, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+            "v_cmp_ngt_f32 vcc, %8, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc\n\t"
+            "v_cmp_ngt_f32 vcc, %9, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+            : "+v"(mask)
+            : "v"(limit), "v"(ap[nb][j][3]), "v"(ap[nb][j][2]), "v"(ap[nb][j][1]), "v"(ap[nb][j][0]), "v"(ap[nb][j - 1][3]),
+              "v"(ap[nb][j - 1][2]), "v"(ap[nb][j - 1][1]), "v"(ap[nb][j - 1][0])
+            : "vcc");
       const uint64_t f = frame0 + (uint64_t)nb * 16 + c;
       if (f < a.n_frames) a.mask[((uint64_t)grp * a.n_frames + f) * 4u + g] = mask;
     }
