@@ -261,8 +261,9 @@ int gmm_prefilter_frames_per_tile() { return kPWaves * SR_P16_NB * 16; }
 // one frame per thread at a time, the feature vector converted to FP64 and kept in registers, one 64-byte piece of
 // the output row per frame.  No barrier and no refill inside the frame loop.
 // LDS image per state: planes [mu_0 | 1/var_0 | mu_1 | 1/var_1 | ... | norm | logw] of NS density slots each.  A lane
-// that evaluates density d reads plane[p][d] with ds_read_b64, whose bank pair is d mod 32: lanes on different
-// densities never conflict and lanes on the same density share one broadcast read, whatever the candidates are.
+// that evaluates density d of state s reads plane[p][(d + s) mod NS] with ds_read_b64, whose bank pair is that slot
+// mod 32: lanes on different densities of a state never conflict, lanes on the same density share one broadcast read,
+// and (phase 2) lanes on the same density index of different states are rotated onto different banks.
 #pragma clang fp contract(off)
 
 #ifndef SR_R_THREADS
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
         n_eval += __builtin_popcount(mask);
         res[j] = 1e10;  // min_score seed (Mixtures.cpp:699)
         if (mask) {     // (empty only for a state without densities)
-          const double score = evaluate(panel_raw + (size_t)j * state_bytes + __builtin_ctz(mask) * 8u);
+          const double score = evaluate(panel_raw + (size_t)j * state_bytes + ((__builtin_ctz(mask) + s0 + j) & (NS - 1)) * 8u);
           if (score < res[j]) res[j] = score;
         }
         rem[j] = mask & (mask - 1);
@@ -418,7 +419,7 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
 #pragma unroll
       for (int j = 0; j < SPW; j++)
         if (j == jsel) rem[j] = msel & (msel - 1);
-      const double score = evaluate(panel_raw + (size_t)jsel * state_bytes + d * 8u);
+      const double score = evaluate(panel_raw + (size_t)jsel * state_bytes + ((d + s0 + jsel) & (NS - 1)) * 8u);
 #pragma unroll
       for (int j = 0; j < SPW; j++)
         if (j == jsel && score < res[j]) res[j] = score;

@@ -281,9 +281,12 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
       double* r = rows.data() + (size_t)ps * planes * NS;
       for (uint32_t i = 0; i < ps_count(ps); i++) {
         const size_t c = (size_t)dens_off[ps / Cs] + 32u * (ps % Cs) + i;
-        for (uint32_t d = 0; d < D; d++) { r[(2 * d) * NS + i] = means[c * D + d]; r[(2 * d + 1) * NS + i] = inv_vars[c * D + d]; }
-        r[(2 * D) * NS + i] = norm[c];
-        r[(2 * D + 1) * NS + i] = logw[c];
+        // density i sits in slot (i + ps) mod NS: the workgroup's 8 states are rotated against each other, so that
+        // lanes on the same density index of different states (the refinement's phase 2) use different LDS banks
+        const uint32_t sl = (i + ps) & (NS - 1);
+        for (uint32_t d = 0; d < D; d++) { r[(2 * d) * NS + sl] = means[c * D + d]; r[(2 * d + 1) * NS + sl] = inv_vars[c * D + d]; }
+        r[(2 * D) * NS + sl] = norm[c];
+        r[(2 * D + 1) * NS + sl] = logw[c];
       }
     }
     HIP_TRY(m->pf_rows.upload(rows.data(), rows.size()));
