@@ -65,6 +65,11 @@ struct DevBuf {
     return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
   }
   void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  // handles own their buffers: whatever a destroy function does not release by name goes with the object
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
 };
 
 struct EventPair { hipEvent_t a, b; int kind; };  // kind 0 = gmm, 1 = search, 2 = prefilter pass, 3 = refinement (inside 0)

@@ -538,3 +538,31 @@ def test_many_utterances_use_the_throughput_slot_layout(tmp_path, oracle_lib, W,
         corpus.close()
         lexh.close()
     o.close()
+
+
+def test_handles_give_their_device_memory_back(tmp_path):
+    """create / use / destroy every handle type repeatedly: free device memory must not creep."""
+    import torch
+
+    lex, spec, mp = _random_setup(tmp_path, 801, 20, 3, 1, 4, 39)
+    feats, off = synth.make_batch(12, 30, 60, 39, seed=2)
+    word_off, aut, sil = lex.flatten()
+    W = lex.n_words
+    lm = np.full((W, W), 3.0, np.float32)
+    btdp = np.array([[3, 0, 30, 5], [1, 0, 40, 2]], np.float32)
+    free = []
+    for it in range(8):
+        with capi.Model.from_mixset(mp, 39) as m:
+            c = m.upload(feats, off)
+            lexh = m.lexicon(word_off, aut, lex.silence_idx, (3.0, 0.0, 30.0), sil)
+            bg = m.bigram(word_off, aut, lex.silence_idx, lm, btdp)
+            c.recognize(lexh, 100.0, 10.0)
+            c.score(capi.GMM_MFMA)
+            c.recognize_bigram(bg, 100.0, capi.FLT_MAX)
+            st, _ = c.align([np.array([sil, 1, 2, 3, sil], np.uint16)] * 12, (3.0, 0.0, 30.0), sil)
+            c.accumulate(st)
+            c.path_scores(st)
+            bg.close(); lexh.close(); c.close()
+        torch.cuda.synchronize()
+        free.append(torch.cuda.mem_get_info()[0])
+    assert free[-1] >= free[2] - (1 << 20), free  # (the first iterations warm up runtime pools)
