@@ -59,13 +59,18 @@ def parse():
 
 def main():
     args = parse()
+    # Only the JSON line may reach stdout: libraries write banners there (RCCL prints its version block when the first
+    # communicator comes up), so fd 1 points at stderr for the whole run and the result goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    distributed = world > 1 or os.environ.get("SR_BENCH_FORCE_DIST") == "1"  # (the env switch rehearses the RCCL path with one rank)
     n_dev = torch.cuda.device_count()
     device = local_rank if args.dist_backend == "nccl" else local_rank % max(1, n_dev)  # gloo rehearsal may share a GPU
     torch.cuda.set_device(device)
@@ -184,8 +189,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline_bigram(args, mixset_path, lex, lm, bg_tdp, feats, frame_off, words, woff)
             else:
                 out["cpu_baseline"] = cpu_baseline(args, mixset_path, lex, tdp, wp, feats, frame_off, words, woff)
-        print(json.dumps(out))
         sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
     corpus.close()
     if bg is not None:
