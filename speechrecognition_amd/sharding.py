@@ -60,7 +60,7 @@ def gather_words(words, word_off, utts, n_utts_total, dist=None, dst=0):
 
 def reduce_timing(elapsed_s, n_frames, dist=None, device=None):
     """bench.py's contract: max over ranks of the step time, sum over ranks of frames."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return float(elapsed_s), float(n_frames)
     import torch
 
