@@ -39,6 +39,8 @@ extern "C" {
 #define SR_EHIP (-2)     /* HIP runtime error */
 #define SR_ENODEV (-3)   /* no usable gfx950 device */
 #define SR_ELIMIT (-4)   /* size outside what the kernels support (message says which) */
+#define SR_ENOMEM (-5)   /* host allocation failed (std::bad_alloc caught at the boundary) */
+#define SR_EINTERNAL (-6) /* any other C++ exception caught at the boundary (message carries what()) */
 
 /* GMM scoring kernels (MixtureModel::score, Mixtures.cpp:737-744) */
 #define SR_GMM_MFMA 0   /* FP64 MFMA contraction + fused min / log-sum epilogue (default; ~1e-15 rel.) */

@@ -2,7 +2,13 @@
 #pragma once
 #include <stdint.h>
 
+#include <exception>
+#include <new>
+#include <stdexcept>
+#include <string>
 #include <vector>
+
+#include "../../include/srgpu.h"
 
 #define SRHOST_POOL_GLOBAL 0   // MixtureModel::GLOBAL_POOLING  (sietill/Mixtures.hpp:20-24)
 #define SRHOST_POOL_MIXTURE 1  // MixtureModel::MIXTURE_POOLING
@@ -24,5 +30,24 @@ const char* load_mixset(const char* path, uint32_t dim, int pooling, MixsetTable
 
 // stores the message for sr_last_error() and returns `code`
 int set_error(int code, const char* msg);
+
+// Exception barrier of the C ABI (include/srgpu.h: "No exceptions cross this boundary"): every extern "C" entry runs its
+// body through this, so that a failed host allocation (std::bad_alloc from new / std::vector), an over-long container
+// (std::length_error), a refused std::thread (std::system_error) or anything else becomes an SR_E* code plus
+// sr_last_error() text instead of std::terminate -> SIGABRT in the caller's process.
+template <typename F>
+int guarded(const char* entry, F&& body) noexcept {
+  try {
+    return body();
+  } catch (const std::bad_alloc&) {
+    return set_error(SR_ENOMEM, (std::string(entry) + ": out of host memory").c_str());
+  } catch (const std::length_error& e) {
+    return set_error(SR_ELIMIT, (std::string(entry) + ": size too large for a host container (" + e.what() + ")").c_str());
+  } catch (const std::exception& e) {
+    return set_error(SR_EINTERNAL, (std::string(entry) + ": unexpected exception: " + e.what()).c_str());
+  } catch (...) {
+    return set_error(SR_EINTERNAL, (std::string(entry) + ": unexpected exception").c_str());
+  }
+}
 
 }  // namespace srhost

@@ -21,10 +21,23 @@ namespace {
 
 struct Reader {
   FILE* f;
-  explicit Reader(const char* path) : f(fopen(path, "rb")) {}
+  uint64_t left = 0;  // bytes not yet consumed: every count read from the file is checked against it BEFORE anything is
+                      // sized from it, so a corrupt header cannot ask for gigabytes (the reference aborts there)
+  explicit Reader(const char* path) : f(fopen(path, "rb")) {
+    if (f && fseek(f, 0, SEEK_END) == 0) {
+      const long n = ftell(f);
+      left = n > 0 ? (uint64_t)n : 0;
+      rewind(f);
+    }
+  }
   ~Reader() { if (f) fclose(f); }
-  bool get(void* dst, size_t n) { return fread(dst, 1, n, f) == n; }
+  bool get(void* dst, size_t n) {
+    if (n > left || fread(dst, 1, n, f) != n) return false;
+    left -= n;
+    return true;
+  }
   template <typename T> bool get(T* v) { return get(v, sizeof(T)); }
+  bool holds(uint64_t count, uint64_t bytes_each) const { return bytes_each == 0 || count <= left / bytes_each; }
 };
 
 struct Accumulators {  // one block of read_accumulator (Mixtures.cpp:104-129)
@@ -35,6 +48,7 @@ struct Accumulators {  // one block of read_accumulator (Mixtures.cpp:104-129)
 
 const char* read_block(Reader& r, uint32_t dim, Accumulators* a) {
   if (!r.get(&a->n)) return "Error reading size";
+  if (!r.holds(a->n, 4 + 8 * (uint64_t)dim + 8)) return "Error reading features";  // count larger than the file
   a->sum.resize((size_t)a->n * dim);
   a->weight.resize(a->n);
   for (uint32_t i = 0; i < a->n; i++) {
@@ -79,6 +93,7 @@ static const char* parse_mixset(const char* path, uint32_t dim, Mixset* ms) {
   if (const char* e = read_block(r, dim, &var_acc)) return e;
   uint32_t n_dens = 0;
   if (!r.get(&n_dens)) return "Error reading density count";
+  if (!r.holds(n_dens, 8)) return "Error reading mean_idx";
   std::vector<Density> dens(n_dens);
   for (auto& d : dens) {
     if (!r.get(&d.mean)) return "Error reading mean_idx";
@@ -88,11 +103,13 @@ static const char* parse_mixset(const char* path, uint32_t dim, Mixset* ms) {
   }
   uint32_t n_mix = 0;
   if (!r.get(&n_mix)) return "Error reading mixture count";
+  if (!r.holds(n_mix, 4)) return "Error reading density count for mixture";
   std::vector<std::vector<Density>>& mixtures = ms->mixtures;
   mixtures.assign(n_mix, std::vector<Density>());
   for (auto& mix : mixtures) {
     uint32_t nd = 0;
     if (!r.get(&nd)) return "Error reading density count for mixture";
+    if (!r.holds(nd, 12)) return "Error reading density idx";
     mix.reserve(nd);
     for (uint32_t i = 0; i < nd; i++) {
       uint32_t di;
@@ -279,6 +296,8 @@ static const char* write_mixset_file(const char* path, const Mixset& ms) {
 
 }  // namespace srhost
 
+using srhost::guarded;
+
 static int tables_to_model(const srhost::MixsetTables& t, uint32_t dim, int max_approx, int device, sr_model** out) {
   int rc = sr_model_create(device, dim, (uint32_t)t.dens_off.size() - 1, t.dens_off.data(), t.means.data(), t.inv_vars.data(),
                            t.norm.data(), t.logw.data(), max_approx, out);
@@ -294,6 +313,7 @@ extern "C" SR_API int sr_model_create_from_statistics(int device, uint32_t dim, 
                                                       const uint32_t* dens_var, const double* mean_acc, const double* mean_w,
                                                       const double* var_acc, const double* var_w, int pooling, int max_approx,
                                                       sr_model** out) {
+  return guarded(__func__, [&]() -> int {
   if (!out) return srhost::set_error(SR_EINVAL, "out is null");
   if (pooling < 0 || pooling > 2) return srhost::set_error(SR_EINVAL, "pooling must be 0 (global), 1 (mixture) or 2 (none)");
   Mixset ms;
@@ -302,24 +322,29 @@ extern "C" SR_API int sr_model_create_from_statistics(int device, uint32_t dim, 
   srhost::MixsetTables t;
   srhost::finalize_mixset(ms, pooling, &t);
   return tables_to_model(t, dim, max_approx, device, out);
+  });
 }
 
 extern "C" SR_API int sr_mixset_write(const char* path, uint32_t dim, uint32_t n_states, const uint32_t* dens_off, uint32_t n_mean,
                                       uint32_t n_var, const uint32_t* dens_mean, const uint32_t* dens_var, const double* mean_acc,
                                       const double* mean_w, const double* var_acc, const double* var_w) {
+  return guarded(__func__, [&]() -> int {
   if (!path) return srhost::set_error(SR_EINVAL, "path is null");
   Mixset ms;
   if (const char* e = srhost::mixset_from_arrays(dim, n_states, dens_off, n_mean, n_var, dens_mean, dens_var, mean_acc, mean_w, var_acc, var_w, &ms))
     return srhost::set_error(SR_EINVAL, e);
   if (const char* e = srhost::write_mixset_file(path, ms)) return srhost::set_error(SR_EINVAL, e);
   return SR_OK;
+  });
 }
 
 extern "C" SR_API int sr_model_load_mixset(const char* path, uint32_t dim, int pooling, int max_approx, int device,
                                            sr_model** out) {
+  return guarded(__func__, [&]() -> int {
   if (!path || !out) return srhost::set_error(SR_EINVAL, "null argument");
   if (pooling < 0 || pooling > 2) return srhost::set_error(SR_EINVAL, "pooling must be 0 (global), 1 (mixture) or 2 (none)");
   srhost::MixsetTables t;
   if (const char* e = srhost::load_mixset(path, dim, pooling, &t)) return srhost::set_error(SR_EINVAL, e);
   return tables_to_model(t, dim, max_approx, device, out);
+  });
 }

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -22,6 +23,7 @@
 #include "kernels.h"
 
 using namespace srgpu;
+using srhost::guarded;
 
 namespace {
 
@@ -549,16 +551,19 @@ extern "C" {
 const char* sr_last_error(void) { return g_err; }
 
 int sr_device_count(int* count) {
+  return guarded(__func__, [&]() -> int {
   if (!count) return fail(SR_EINVAL, "count is null");
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess) { *count = 0; return fail(SR_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
   *count = n;
   return SR_OK;
+  });
 }
 
 int sr_model_create(int device, uint32_t dim, uint32_t n_states, const uint32_t* dens_off, const double* means,
                     const double* inv_vars, const double* norm, const double* logw, int max_approx, sr_model** out) {
+  return guarded(__func__, [&]() -> int {
   if (!out) return fail(SR_EINVAL, "out is null");
   *out = nullptr;
   if (!dens_off || !means || !inv_vars || !norm || !logw) return fail(SR_EINVAL, "null model table");
@@ -579,6 +584,7 @@ int sr_model_create(int device, uint32_t dim, uint32_t n_states, const uint32_t*
     return fail(SR_ENODEV, "device %d is %s; libsrgpu is built for gfx950 (MI355X) only", device, prop.gcnArchName);
   HIP_TRY(hipSetDevice(device));
   sr_model* m = new sr_model();
+  std::unique_ptr<sr_model, int (*)(sr_model*)> own(m, sr_model_destroy);  // released on success; an exception frees it
   m->device = device; m->dim = dim; m->n_states = n_states; m->n_dens = C; m->max_approx = max_approx != 0;
   m->ksteps = ks;
   m->ld = (n_states + 7u) & ~7u;  // 64-byte rows pieces for the kernels that write 8 states per thread
@@ -620,7 +626,7 @@ int sr_model_create(int device, uint32_t dim, uint32_t n_states, const uint32_t*
         rc = fail(SR_EHIP, "tying upload: %s", hipGetErrorString(e));
     }
   } while (0);
-  if (rc != SR_OK) { sr_model_destroy(m); return rc; }
+  if (rc != SR_OK) return rc;
   const char* env = getenv("SRGPU_SCORE_CHUNK_MB");
   // score workspace per chunk: 16 GiB by default (two such buffers only when a corpus needs more than one
   // chunk).  Bigger chunks mean fewer, longer GMM launches -- measured 68 vs 65 TFLOP/s at 4 GiB -- and
@@ -628,11 +634,13 @@ int sr_model_create(int device, uint32_t dim, uint32_t n_states, const uint32_t*
   const size_t chunk_bytes = (env ? (size_t)atol(env) : 16384) << 20;
   m->chunk_frames = std::max<size_t>(1, chunk_bytes / ((size_t)m->ld * sizeof(double)));
   if (const char* ov = getenv("SRGPU_OVERLAP")) m->overlap = atoi(ov) != 0;
-  *out = m;
+  *out = own.release();
   return SR_OK;
+  });
 }
 
 int sr_model_destroy(sr_model* m) {
+  return guarded(__func__, [&]() -> int {
   if (!m) return SR_OK;
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
@@ -649,17 +657,21 @@ int sr_model_destroy(sr_model* m) {
   if (m->s_search) (void)hipStreamDestroy(m->s_search);
   delete m;
   return SR_OK;
+  });
 }
 
 int sr_model_info(const sr_model* m, uint32_t* dim, uint32_t* n_states, uint64_t* n_densities) {
+  return guarded(__func__, [&]() -> int {
   if (!m) return fail(SR_EINVAL, "null model handle");
   if (dim) *dim = m->dim;
   if (n_states) *n_states = m->n_states;
   if (n_densities) *n_densities = m->n_dens;
   return SR_OK;
+  });
 }
 
 int sr_corpus_upload(sr_model* m, const float* feats, const uint64_t* frame_off, uint32_t n_utts, sr_corpus** out) {
+  return guarded(__func__, [&]() -> int {
   if (!out) return fail(SR_EINVAL, "out is null");
   *out = nullptr;
   int rc = check_model(m);
@@ -675,20 +687,21 @@ int sr_corpus_upload(sr_model* m, const float* feats, const uint64_t* frame_off,
   const uint64_t F = frame_off[n_utts];
   if (F > 0 && !feats) return fail(SR_EINVAL, "feats is null");
   sr_corpus* c = new sr_corpus();
+  std::unique_ptr<sr_corpus, int (*)(sr_corpus*)> own(c, sr_corpus_destroy);
   c->model = m; c->n_utts = n_utts; c->n_frames = F;
   c->frame_off.assign(frame_off, frame_off + n_utts + 1);
   hipError_t e;
   if ((e = c->feats.ensure((size_t)F * m->dim + 64)) != hipSuccess ||
       (F > 0 && (e = hipMemcpy(c->feats.p, feats, (size_t)F * m->dim * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) ||
-      (e = c->d_frame_off.upload(frame_off, n_utts + 1)) != hipSuccess) {
-    sr_corpus_destroy(c);
+      (e = c->d_frame_off.upload(frame_off, n_utts + 1)) != hipSuccess)
     return fail(SR_EHIP, "corpus upload: %s", hipGetErrorString(e));
-  }
-  *out = c;
+  *out = own.release();
   return SR_OK;
+  });
 }
 
 int sr_corpus_destroy(sr_corpus* c) {
+  return guarded(__func__, [&]() -> int {
   if (!c) return SR_OK;
   if (c->model) { (void)hipSetDevice(c->model->device); (void)hipDeviceSynchronize(); }
   c->feats.release(); c->d_frame_off.release(); c->tb_score.release(); c->tb_word.release(); c->tb_bkp.release();
@@ -700,9 +713,11 @@ int sr_corpus_destroy(sr_corpus* c) {
   c->w_mean.release(); c->w_var.release(); c->sort_temp.release();
   delete c;
   return SR_OK;
+  });
 }
 
 int sr_score_corpus(sr_model* m, sr_corpus* c, int gmm_kernel, double* out) {
+  return guarded(__func__, [&]() -> int {
   int rc = check_model(m);
   if (rc) return rc;
   if (!c || c->model != m) return fail(SR_EINVAL, "corpus does not belong to this model");
@@ -721,28 +736,32 @@ int sr_score_corpus(sr_model* m, sr_corpus* c, int gmm_kernel, double* out) {
   }
   if (m->profiling) m->prof.frames += F;
   return SR_OK;
+  });
 }
 
 int sr_score_frames(sr_model* m, const float* feats, uint64_t n_frames, int gmm_kernel, double* out) {
+  return guarded(__func__, [&]() -> int {
   const uint64_t off[2] = {0, n_frames};
   int rc = check_model(m);
   if (rc) return rc;
+  if (n_frames > 0 && (!feats || !out)) return fail(SR_EINVAL, "%s is null", feats ? "out" : "feats");
+  if (n_frames > (std::numeric_limits<size_t>::max() / sizeof(float) - 64) / m->dim)
+    return fail(SR_ELIMIT, "n_frames %llu x dim %u overflows the address space", (unsigned long long)n_frames, m->dim);
   // scoring has no 16-bit frame limit: bypass the per-utterance check by uploading directly
   sr_corpus* c = new sr_corpus();
+  std::unique_ptr<sr_corpus, int (*)(sr_corpus*)> own(c, sr_corpus_destroy);
   c->model = m; c->n_utts = 1; c->n_frames = n_frames; c->frame_off.assign(off, off + 2);
   hipError_t e;
   if ((e = c->feats.ensure((size_t)n_frames * m->dim + 64)) != hipSuccess ||
-      (n_frames > 0 && (e = hipMemcpy(c->feats.p, feats, (size_t)n_frames * m->dim * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess)) {
-    sr_corpus_destroy(c);
+      (n_frames > 0 && (e = hipMemcpy(c->feats.p, feats, (size_t)n_frames * m->dim * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess))
     return fail(SR_EHIP, "feature upload: %s", hipGetErrorString(e));
-  }
-  rc = sr_score_corpus(m, c, gmm_kernel, out);
-  sr_corpus_destroy(c);
-  return rc;
+  return sr_score_corpus(m, c, gmm_kernel, out);
+  });
 }
 
 int sr_lexicon_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, const uint16_t* automaton,
                       uint32_t silence_idx, const double tdp[3], uint16_t silence_state, sr_lexicon** out) {
+  return guarded(__func__, [&]() -> int {
   if (!out) return fail(SR_EINVAL, "out is null");
   *out = nullptr;
   int rc = check_model(m);
@@ -817,6 +836,7 @@ int sr_lexicon_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, c
     f_orig[q] = p | (base << 16);
   }
   sr_lexicon* l = new sr_lexicon();
+  std::unique_ptr<sr_lexicon, int (*)(sr_lexicon*)> own(l, sr_lexicon_destroy);
   l->f_n = Pn; l->f_init = new_id[0]; l->f_init_end = (info[0] >> 18) & 1u;
   l->model = m; l->n_words = n_words; l->n_slots = P; l->silence_idx = silence_idx; l->silence_state = silence_state;
   l->tdp[0] = tdp[0]; l->tdp[1] = tdp[1]; l->tdp[2] = tdp[2];
@@ -824,25 +844,27 @@ int sr_lexicon_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, c
   if ((e = l->slot_info.upload(info.data(), P)) != hipSuccess || (e = l->slot_word.upload(sword.data(), P)) != hipSuccess ||
       (e = l->word_end_slot.upload(wend.data(), n_words)) != hipSuccess || (e = l->f_state.upload(f_state.data(), Pn)) != hipSuccess ||
       (e = l->f_pred.upload(f_pred.data(), Pn)) != hipSuccess || (e = l->f_orig.upload(f_orig.data(), Pn)) != hipSuccess ||
-      (e = l->f_type.upload(f_type.data(), Pn / 64)) != hipSuccess || (e = l->f_word.upload(f_word.data(), Pn)) != hipSuccess) {
-    sr_lexicon_destroy(l);
+      (e = l->f_type.upload(f_type.data(), Pn / 64)) != hipSuccess || (e = l->f_word.upload(f_word.data(), Pn)) != hipSuccess)
     return fail(SR_EHIP, "lexicon upload: %s", hipGetErrorString(e));
-  }
-  *out = l;
+  *out = own.release();
   return SR_OK;
+  });
 }
 
 int sr_lexicon_destroy(sr_lexicon* l) {
+  return guarded(__func__, [&]() -> int {
   if (!l) return SR_OK;
   if (l->model) { (void)hipSetDevice(l->model->device); (void)hipDeviceSynchronize(); }
   l->slot_info.release(); l->slot_word.release(); l->word_end_slot.release();
   l->f_state.release(); l->f_pred.release(); l->f_orig.release(); l->f_type.release(); l->f_word.release();
   delete l;
   return SR_OK;
+  });
 }
 
 int sr_recognize_corpus(sr_model* m, sr_corpus* c, sr_lexicon* l, const sr_search_params* p, uint32_t* out_words,
                         uint64_t* out_word_off, double* tb_score, uint16_t* tb_word, uint16_t* tb_bkp) {
+  return guarded(__func__, [&]() -> int {
   int rc = check_model(m);
   if (rc) return rc;
   if (!c || c->model != m) return fail(SR_EINVAL, "corpus does not belong to this model");
@@ -908,10 +930,12 @@ int sr_recognize_corpus(sr_model* m, sr_corpus* c, sr_lexicon* l, const sr_searc
   if (tb_bkp) HIP_TRY(hipMemcpy(tb_bkp, c->tb_bkp.p, sizeof(uint16_t) * (F + U), hipMemcpyDeviceToHost));
   if (m->profiling) m->prof.frames += F;
   return SR_OK;
+  });
 }
 
 int sr_bigram_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, const uint16_t* mixtures,
                      uint32_t silence_word, const float* lm, const float tdp[8], sr_bigram** out) {
+  return guarded(__func__, [&]() -> int {
   if (!out) return fail(SR_EINVAL, "out is null");
   *out = nullptr;
   int rc = check_model(m);
@@ -950,21 +974,22 @@ int sr_bigram_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, co
       rowmax[h] = (v > rowmax[h] || v != v) ? v : rowmax[h];
     }
   sr_bigram* b = new sr_bigram();
+  std::unique_ptr<sr_bigram, int (*)(sr_bigram*)> own(b, sr_bigram_destroy);
   b->model = m; b->n_words = W; b->silence = silence_word; b->n_positions = P2;
   memcpy(b->tdp, tdp, sizeof(b->tdp));
   hipError_t e;
   if ((e = b->slot_off.upload(slot_off.data(), slot_off.size())) != hipSuccess ||
       (e = b->slot_mix.upload(slot_mix.data(), slot_mix.size())) != hipSuccess ||
       (e = b->mixtures.upload(mixtures, word_off[W])) != hipSuccess || (e = b->lmT.upload(lmT.data(), lmT.size())) != hipSuccess ||
-      (e = b->lm_rowmin.upload(rowmin.data(), W)) != hipSuccess || (e = b->lm_rowmax.upload(rowmax.data(), W)) != hipSuccess) {
-    sr_bigram_destroy(b);
+      (e = b->lm_rowmin.upload(rowmin.data(), W)) != hipSuccess || (e = b->lm_rowmax.upload(rowmax.data(), W)) != hipSuccess)
     return fail(SR_EHIP, "bigram upload: %s", hipGetErrorString(e));
-  }
-  *out = b;
+  *out = own.release();
   return SR_OK;
+  });
 }
 
 int sr_bigram_destroy(sr_bigram* b) {
+  return guarded(__func__, [&]() -> int {
   if (!b) return SR_OK;
   if (b->model) { (void)hipSetDevice(b->model->device); (void)hipDeviceSynchronize(); }
   b->slot_off.release(); b->slot_mix.release(); b->mixtures.release(); b->lmT.release(); b->lm_rowmin.release(); b->lm_rowmax.release();
@@ -972,10 +997,12 @@ int sr_bigram_destroy(sr_bigram* b) {
   b->out_word.release(); b->out_time.release(); b->out_score.release(); b->out_count.release(); b->out_flags.release();
   delete b;
   return SR_OK;
+  });
 }
 
 int sr_recognize_bigram_corpus(sr_model* m, sr_corpus* c, sr_bigram* b, const sr_bigram_params* p, uint32_t* out_word,
                                float* out_score, uint32_t* out_time, uint64_t* out_off) {
+  return guarded(__func__, [&]() -> int {
   int rc = check_model(m);
   if (rc) return rc;
   if (!c || c->model != m) return fail(SR_EINVAL, "corpus does not belong to this model");
@@ -1052,16 +1079,18 @@ int sr_recognize_bigram_corpus(sr_model* m, sr_corpus* c, sr_bigram* b, const sr
   }
   if (m->profiling) m->prof.frames += F;
   return SR_OK;
+  });
 }
 
 int sr_recognize_batch(sr_model* m, sr_lexicon* l, const sr_search_params* p, const float* feats,
                        const uint64_t* frame_off, uint32_t n_utts, uint32_t* out_words, uint64_t* out_word_off) {
+  return guarded(__func__, [&]() -> int {
   sr_corpus* c = nullptr;
   int rc = sr_corpus_upload(m, feats, frame_off, n_utts, &c);
   if (rc) return rc;
-  rc = sr_recognize_corpus(m, c, l, p, out_words, out_word_off, nullptr, nullptr, nullptr);
-  sr_corpus_destroy(c);
-  return rc;
+  std::unique_ptr<sr_corpus, int (*)(sr_corpus*)> own(c, sr_corpus_destroy);
+  return sr_recognize_corpus(m, c, l, p, out_words, out_word_off, nullptr, nullptr, nullptr);
+  });
 }
 
 static int align_common(sr_model* m, sr_corpus* c, const uint16_t* automata, const uint64_t* aut_off, const double tdp[3],
@@ -1170,16 +1199,21 @@ static int align_common(sr_model* m, sr_corpus* c, const uint16_t* automata, con
 
 int sr_align_corpus(sr_model* m, sr_corpus* c, const uint16_t* automata, const uint64_t* aut_off, const double tdp[3],
                     uint16_t silence_state, int gmm_kernel, uint16_t* out_states, double* out_cost) {
+  return guarded(__func__, [&]() -> int {
   return align_common(m, c, automata, aut_off, tdp, silence_state, 0.0, false, gmm_kernel, out_states, out_cost);
+  });
 }
 
 int sr_align_corpus_pruned(sr_model* m, sr_corpus* c, const uint16_t* automata, const uint64_t* aut_off,
                            const double tdp[3], uint16_t silence_state, double pruning_threshold, int gmm_kernel,
                            uint16_t* out_states, double* out_cost) {
+  return guarded(__func__, [&]() -> int {
   return align_common(m, c, automata, aut_off, tdp, silence_state, pruning_threshold, true, gmm_kernel, out_states, out_cost);
+  });
 }
 
 int sr_path_scores_corpus(sr_model* m, sr_corpus* c, const uint16_t* states, int gmm_kernel, double* out) {
+  return guarded(__func__, [&]() -> int {
   int rc = check_model(m);
   if (rc) return rc;
   if (!c || c->model != m) return fail(SR_EINVAL, "corpus does not belong to this model");
@@ -1212,9 +1246,11 @@ int sr_path_scores_corpus(sr_model* m, sr_corpus* c, const uint16_t* states, int
   HIP_TRY(hipMemcpy(out, c->path_scores.p, sizeof(double) * F, hipMemcpyDeviceToHost));
   if (m->profiling) m->prof.frames += F;
   return SR_OK;
+  });
 }
 
 int sr_model_set_tying(sr_model* m, uint32_t n_mean, uint32_t n_var, const uint32_t* dens_mean, const uint32_t* dens_var) {
+  return guarded(__func__, [&]() -> int {
   int rc = check_model(m);
   if (rc) return rc;
   if (!dens_mean || !dens_var) return fail(SR_EINVAL, "null tying table");
@@ -1224,17 +1260,21 @@ int sr_model_set_tying(sr_model* m, uint32_t n_mean, uint32_t n_var, const uint3
   HIP_TRY(m->dens_var.upload(dens_var, m->n_dens));
   m->n_mean = n_mean; m->n_var = n_var;
   return SR_OK;
+  });
 }
 
 int sr_model_tying_info(const sr_model* m, uint32_t* n_mean, uint32_t* n_var) {
+  return guarded(__func__, [&]() -> int {
   if (!m) return fail(SR_EINVAL, "null model handle");
   if (n_mean) *n_mean = m->n_mean;
   if (n_var) *n_var = m->n_var;
   return SR_OK;
+  });
 }
 
 int sr_accumulate_corpus(sr_model* m, sr_corpus* c, const uint16_t* states, int first_pass, int max_approx, double* mean_acc,
                          double* mean_w, double* var_acc, double* var_w) {
+  return guarded(__func__, [&]() -> int {
   int rc = check_model(m);
   if (rc) return rc;
   if (!c || c->model != m) return fail(SR_EINVAL, "corpus does not belong to this model");
@@ -1289,24 +1329,30 @@ int sr_accumulate_corpus(sr_model* m, sr_corpus* c, const uint16_t* states, int 
   HIP_TRY(hipMemcpy(var_acc, c->acc_var.p, sizeof(double) * (size_t)m->n_var * D, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(var_w, c->w_var.p, sizeof(double) * m->n_var, hipMemcpyDeviceToHost));
   return SR_OK;
+  });
 }
 
 int sr_probe_fp16_denormals(int device, int* preserved) {
+  return guarded(__func__, [&]() -> int {
   if (!preserved) return fail(SR_EINVAL, "preserved is null");
   HIP_TRY(hipSetDevice(device));
   bool ok = false;
   HIP_TRY(probe_fp16_denormals(nullptr, &ok));
   *preserved = ok ? 1 : 0;
   return SR_OK;
+  });
 }
 
 int sr_profile_enable(sr_model* m, int on) {
+  return guarded(__func__, [&]() -> int {
   if (!m) return fail(SR_EINVAL, "null model handle");
   m->profiling = on != 0;
   return SR_OK;
+  });
 }
 
 int sr_profile_reset(sr_model* m) {
+  return guarded(__func__, [&]() -> int {
   int rc = check_model(m);
   if (rc) return rc;
   HIP_TRY(hipDeviceSynchronize());
@@ -1316,9 +1362,11 @@ int sr_profile_reset(sr_model* m) {
   HIP_TRY(m->pf_counter.ensure(1));
   HIP_TRY(hipMemset(m->pf_counter.p, 0, sizeof(unsigned long long)));
   return SR_OK;
+  });
 }
 
 int sr_profile_read(sr_model* m, sr_profile* out) {
+  return guarded(__func__, [&]() -> int {
   int rc = check_model(m);
   if (rc) return rc;
   if (!out) return fail(SR_EINVAL, "out is null");
@@ -1341,6 +1389,7 @@ int sr_profile_read(sr_model* m, sr_profile* out) {
   }
   *out = m->prof;
   return SR_OK;
+  });
 }
 
 }  // extern "C"

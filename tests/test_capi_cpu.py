@@ -61,3 +61,67 @@ def test_mixset_loader_rejects_malformed_files(built_lib, tmp_path):
     p.write_bytes(b"MIXSET\0\0" + np.array([2, 38], dtype="<u4").tobytes())
     with pytest.raises(capi.SrError, match="Invalid dimension"):
         capi.Model.from_mixset(str(p), 39)
+
+
+def _mixset_header(dim):
+    return b"MIXSET\0\0" + np.array([2, dim], dtype="<u4").tobytes()
+
+
+def test_absurd_counts_in_a_model_file_are_errors_not_aborts(built_lib, tmp_path):
+    """include/srgpu.h: "No exceptions cross this boundary".  A corrupt count used to size a std::vector straight from
+    the file (4 Gi accumulators x 39 doubles -> std::bad_alloc / std::length_error -> std::terminate -> SIGABRT in the
+    host process).  Counts are now checked against the bytes left in the file, and every entry point has a catch-all."""
+    from speechrecognition_amd import capi
+    p = tmp_path / "huge.mix"
+    # (a) mean-accumulator count 0xFFFFFFFF with nothing behind it
+    p.write_bytes(_mixset_header(39) + np.array([0xFFFFFFFF], dtype="<u4").tobytes())
+    with pytest.raises(capi.SrError, match="Error reading features") as e:
+        capi.Model.from_mixset(str(p), 39)
+    assert e.value.code == -1
+    # (b) both accumulator blocks empty, density count absurd
+    p.write_bytes(_mixset_header(39) + np.array([0, 0, 0xFFFFFFF0], dtype="<u4").tobytes())
+    with pytest.raises(capi.SrError, match="Error reading mean_idx"):
+        capi.Model.from_mixset(str(p), 39)
+    # (c) absurd mixture count, (d) absurd per-mixture density count
+    p.write_bytes(_mixset_header(39) + np.array([0, 0, 0, 0xFFFFFFF0], dtype="<u4").tobytes())
+    with pytest.raises(capi.SrError, match="Error reading density count for mixture"):
+        capi.Model.from_mixset(str(p), 39)
+    p.write_bytes(_mixset_header(39) + np.array([0, 0, 0, 1, 0xFFFFFFF0], dtype="<u4").tobytes())
+    with pytest.raises(capi.SrError, match="Error reading density idx"):
+        capi.Model.from_mixset(str(p), 39)
+
+
+def test_exception_barrier_turns_bad_alloc_into_a_status(built_lib):
+    """Forces a host allocation that cannot succeed through an entry point that needs no GPU: statistics with 2^32-1
+    accumulator rows x 63 dimensions (2 TB of doubles).  The call must come back with SR_ENOMEM / SR_ELIMIT and a
+    message -- in a child process, so that a regression (SIGABRT) fails this test instead of killing pytest."""
+    import sys
+    code = r"""
+import ctypes as C, numpy as np, sys
+sys.path.insert(0, %r)
+from speechrecognition_amd import capi
+L = capi.lib()
+off = np.zeros(2, np.uint32); one = np.zeros(1, np.uint32); d = np.zeros(64, np.float64)
+out = C.c_void_p()
+rc = L.sr_model_create_from_statistics(0, 63, 1, off.ctypes.data, 0xFFFFFFFF, 1, one.ctypes.data, one.ctypes.data,
+                                       d.ctypes.data, d.ctypes.data, d.ctypes.data, d.ctypes.data, 2, 1, C.byref(out))
+print(rc, L.sr_last_error().decode())
+sys.exit(0 if rc in (-4, -5) else 3)
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "sr_model_create_from_statistics" in r.stdout
+
+
+def test_build_stamps_follow_content_not_mtime(built_lib):
+    """An object compiled while a header was being edited must be rebuilt: staleness is decided by a content hash taken
+    before the compiler starts (speechrecognition_amd/build.py), never by mtime."""
+    from speechrecognition_amd import build
+    obj = os.path.join(build.CSRC, "build", "mixset.cpp.o")
+    stamp = open(obj + ".stamp").read()
+    assert len(stamp) == 64
+    lib_stamp = open(build.LIB + ".stamp").read()
+    os.utime(os.path.join(build.CSRC, "kernels.h"))           # newer mtime, same bytes: nothing to do
+    before = os.path.getmtime(obj)
+    build.build()
+    assert os.path.getmtime(obj) == before and open(build.LIB + ".stamp").read() == lib_stamp
