@@ -97,9 +97,59 @@ def make_case(name, lex, spec, feats, beam=200.0, wp=10.0, tdp=(3.0, 0.0, 30.0),
     print(f"{name}: T={feats.shape[0]} S={lex.n_states} words={len(words)} -> {os.path.getsize(path)} B")
 
 
+def global_pooling_case():
+    """pooling = 0 (GLOBAL_POOLING, Mixtures.cpp:431-450): the corpus-level mean enters the ONE variance row 0; every
+    other variance row is never computed and stays at read()'s zero-initialised vars_/vars_inv_/norm_ (:776-778) --
+    one mixture here references row 1 to pin exactly that.  Also the EM iteration under this tying: accumulate a state
+    path with the reference, MixtureModel::write it (rows nobody references are dropped and renumbered), load the
+    written file again with global pooling and score."""
+    lex = synth.make_lexicon(4, 3, 1)
+    spec = synth.make_mixset(lex.n_states, 3, 39, seed=43)
+    spec.dens_var[:] = 0
+    spec.dens_var[spec.mixtures[5]] = 1            # never finalised under global pooling
+    gm = spec.mean_acc.sum(axis=0) / spec.mean_w.sum()
+    rng = np.random.default_rng(44)
+    spec.var_acc[0] = (0.8 + np.abs(rng.standard_normal(39)) + gm ** 2) * spec.var_w[0]
+    feats = synth.make_features(60, 39, 45)
+    make_case("global_pooling", lex, spec, feats, beam=150.0, pooling=po.POOL_GLOBAL, align_words=[2, 4],
+              note="GLOBAL_POOLING: variance row 0 from the corpus mean, row 1 left at zero")
+    # EM iteration under the same tying
+    tmp = tempfile.mkdtemp()
+    mp, cp = os.path.join(tmp, "m.mix"), os.path.join(tmp, "c.json")
+    synth.write_mixset(mp, spec)
+    synth.write_config(cp, mp)
+    states = rng.integers(0, lex.n_states, size=len(feats)).astype(np.uint16)
+    ref = po.Reference(cp, 39, lex, pooling=po.POOL_GLOBAL)
+    orc = po.Oracle(mp, 39, lex, pooling=po.POOL_GLOBAL)
+    outp = os.path.join(tmp, "acc.mix")
+    ref.accumulate_and_write(feats, states, outp)
+    got = synth.read_mixset(outp)
+    a, w, v, vw = orc.accumulate(feats, states)
+    keep = np.unique(spec.dens_var)
+    assert np.array_equal(got.mean_acc, a) and np.array_equal(got.mean_w, w)
+    assert np.array_equal(got.var_acc, v[keep]) and np.array_equal(got.var_w, vw[keep])
+    ref.close(); orc.close()
+    cp2 = os.path.join(tmp, "c2.json")
+    synth.write_config(cp2, outp)
+    ref2 = po.Reference(cp2, 39, lex, pooling=po.POOL_GLOBAL)
+    orc2 = po.Oracle(outp, 39, lex, pooling=po.POOL_GLOBAL)
+    after = ref2.score_matrix(feats[:32])
+    assert np.array_equal(after.view(np.uint64), orc2.score_matrix(feats[:32]).view(np.uint64))
+    ref2.close(); orc2.close()
+    z = dict(np.load(os.path.join(OUT, "global_pooling.npz")))
+    z.update(em_states=states, em_var_keep=keep, em_mean_acc=got.mean_acc, em_mean_w=got.mean_w, em_var_acc=got.var_acc,
+             em_var_w=got.var_w, em_file_sha256=hashlib.sha256(open(outp, "rb").read()).hexdigest(),
+             em_scores_after=after)
+    np.savez_compressed(os.path.join(OUT, "global_pooling.npz"), **z)
+    print("global_pooling: + EM iteration (accumulate -> write -> reload with pooling=0)")
+
+
 def main():
     assert po.reference_available(), "build oracle/_ref first (make -C oracle)"
     os.makedirs(OUT, exist_ok=True)
+    if "--only-global-pooling" in sys.argv:  # added in round 2; the other fixtures are left as committed
+        global_pooling_case()
+        return
 
     # cfg1 of BASELINE.json: 3-state monophone + silence, 1-mix, 100 frames, D=39
     lex = synth.make_lexicon(1, 3, 1)
@@ -223,6 +273,7 @@ def main():
                         out=np.asarray(outs, dtype=np.uint16))
     ref.close()
     print("edit_distance: 40 cases")
+    global_pooling_case()
 
 
 if __name__ == "__main__":

@@ -127,6 +127,7 @@ struct DecodeArgs {
   uint32_t* out_words;          // utterance u writes its words at out_words[frame_off[u] ...]
   uint32_t* out_count;          // [n_utts_total]
   uint32_t* out_flags;          // [n_utts_total] bit0: slow (sequential-emulation) path was taken
+  uint32_t force_general;       // skip the fast kernel: every utterance goes through decode_kernel<.., REPLAY = true>
 };
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream);       // fast variant, then the replay variant for flagged utterances
 hipError_t launch_decode_fast(const DecodeArgs& a, hipStream_t stream);

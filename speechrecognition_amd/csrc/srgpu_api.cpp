@@ -891,6 +891,8 @@ int sr_recognize_corpus(sr_model* m, sr_corpus* c, sr_lexicon* l, const sr_searc
   da.fast.chunk_type = l->f_type.p; da.fast.word = l->f_word.p; da.fast.init_slot = l->f_init; da.fast.init_is_end = l->f_init_end;
   da.ld = m->ld; da.frame_off = c->d_frame_off.p;
   da.am_threshold = p->am_threshold; da.word_penalty = p->word_penalty;
+  if (p->flags & ~SR_SEARCH_GENERAL_KERNEL) return fail(SR_EINVAL, "unknown sr_search_params.flags 0x%x", (unsigned)p->flags);
+  da.force_general = (p->flags & SR_SEARCH_GENERAL_KERNEL) ? 1u : 0u;
   da.tb_score = c->tb_score.p; da.tb_word = c->tb_word.p; da.tb_bkp = c->tb_bkp.p;
   da.out_words = c->out_words.p; da.out_count = c->out_count.p; da.out_flags = c->out_flags.p;
 

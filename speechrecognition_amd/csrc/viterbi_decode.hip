@@ -144,7 +144,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeArgs a) {
   uint16_t* bk = reinterpret_cast<uint16_t*>(e_first + 12);         // [PP] back pointers (start frame of the word)
 
   const uint32_t u = a.utt_first + blockIdx.x;
-  if (REPLAY && !(a.out_flags[u] & 2u)) return;  // wave-uniform: nothing to redo for this utterance
+  if (REPLAY && !a.force_general && !(a.out_flags[u] & 2u)) return;  // wave-uniform: nothing to redo for this utterance
   const uint64_t f0 = a.frame_off[u];
   const uint32_t T = (uint32_t)(a.frame_off[u + 1] - f0);
   const double* row0 = a.scores + (f0 - a.frame_base) * a.ld;
@@ -394,7 +394,7 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream) {
   const dim3 grid(a.n_utts);
   // fast variant first (viterbi_fast.hip); then the replay variant, whose workgroups exit at once unless the fast
   // one flagged their utterance (negative emission cost)
-  {
+  if (!a.force_general) {
     hipError_t e = launch_decode_fast(a, stream);
     if (e != hipSuccess) return e;
   }

@@ -127,3 +127,31 @@ def test_oracle_accumulate_matches_reference_golden(tag, first_pass, max_approx,
     assert np.array_equal(a.view(np.uint64), z[f"{tag}_mean_acc"].view(np.uint64)) and np.array_equal(w, z[f"{tag}_mean_w"])
     assert np.array_equal(v[keep].view(np.uint64), z[f"{tag}_var_acc"].view(np.uint64)) and np.array_equal(vw[keep], z[f"{tag}_var_w"])
     o.close()
+
+
+def test_oracle_global_pooling_em_iteration(oracle_lib, tmp_path):
+    """pooling = 0 through the EM side of the oracle: accumulators equal to what the REFERENCE wrote
+    (tests/golden/global_pooling.npz, em_*), and the scores after reloading those statistics with global pooling."""
+    c = Case("global_pooling", tmp_path)
+    z = c.z
+    o = c.oracle(oracle_lib)
+    a, w, v, vw = o.accumulate(c.feats, z["em_states"])
+    o.close()
+    keep = z["em_var_keep"]
+    assert np.array_equal(a.view(np.uint64), z["em_mean_acc"].view(np.uint64)) and np.array_equal(w, z["em_mean_w"])
+    assert np.array_equal(v[keep].view(np.uint64), z["em_var_acc"].view(np.uint64)) and np.array_equal(vw[keep], z["em_var_w"])
+    # the file MixtureModel::write produced (rows renumbered), reloaded with pooling = 0
+    flat = np.asarray([d for m in c.spec.mixtures for d in m], dtype=np.int64)
+    remap = np.full(len(c.spec.var_w), -1, np.int64)
+    remap[keep] = np.arange(len(keep))
+    spec2 = synth.MixsetSpec(c.dim, z["em_mean_acc"], z["em_mean_w"], z["em_var_acc"], z["em_var_w"], c.spec.dens_mean[flat],
+                             remap[c.spec.dens_var[flat]].astype(np.uint32),
+                             [list(range(int(a0), int(b0))) for a0, b0 in zip(z["model_mix_off"][:-1], z["model_mix_off"][1:])])
+    p2 = str(tmp_path / "em.mix")
+    synth.write_mixset(p2, spec2)
+    import hashlib
+    assert hashlib.sha256(open(p2, "rb").read()).hexdigest() == str(z["em_file_sha256"])  # same bytes as the reference's file
+    o2 = oracle_lib.Oracle(p2, c.dim, c.lex, pooling=0)
+    got = o2.score_matrix(c.feats[:32])
+    o2.close()
+    assert np.array_equal(got.view(np.uint64), z["em_scores_after"].view(np.uint64))
