@@ -262,8 +262,25 @@ int gmm_prefilter_frames_per_tile() { return kPWaves * SR_P16_NB * 16; }
 // the output row per frame.  No barrier and no refill inside the frame loop.
 // LDS image per state: planes [mu_0 | 1/var_0 | mu_1 | 1/var_1 | ... | norm | logw] of NS density slots each.  A lane
 // that evaluates density d of state s reads plane[p][(d + s) mod NS] with ds_read_b64, whose bank pair is that slot
-// mod 32: lanes on different densities of a state never conflict, lanes on the same density share one broadcast read,
-// and (phase 2) lanes on the same density index of different states are rotated onto different banks.
+// mod 32: lanes on different densities of ONE state never conflict and lanes on the same density share one broadcast
+// read -- so every wave instruction below evaluates candidates of a single state.
+//
+// Work layout (round 2).  About 7 % of the (frame, state) pairs have more than one candidate.  Letting the lanes that
+// hold such pairs loop (round 1) cost 0.44 extra wave-evaluations per pair-wave for 0.087 extra candidates, because a
+// wave waits for its unluckiest lane.  Now:
+//   main pass   every lane evaluates the FIRST candidate of each of its 8 states (no divergence) and writes the row
+//               piece; a lane whose pair has further candidates appends its frame to a small wave-private list of that
+//               state (v_cmp ballot + mbcnt, one 4-byte store).
+//   level 1     whenever a state's list holds 64 frames the wave evaluates the SECOND candidate of those 64 pairs --
+//               one state, 64 different frames, fully dense -- and lowers the table entry where it wins.  The frames
+//               are recent, so their features, masks and row pieces still sit in L2 / Infinity Cache.  Pairs with a
+//               third candidate (1 % of all) move on to the level-2 list of the state.
+//   level 2     64 such pairs at a time; the lanes loop over what is left of their masks (the only divergent code, on
+//               about 1 % of the pairs).
+//   lists are flushed at the end of the frame range.  The result does not depend on the order of evaluation: it is
+//   the minimum under strict '<' seeded with 1e10 (Mixtures.cpp:696-713), a NaN never wins, and a score is never -0
+//   (l0 starts at +0, so dist and norm + dist/2 are never -0, and a - b is -0 only for a = -0): equal scores have equal
+//   bits.
 #pragma clang fp contract(off)
 
 #ifndef SR_R_THREADS
@@ -275,6 +292,14 @@ int gmm_prefilter_frames_per_tile() { return kPWaves * SR_P16_NB * 16; }
 static constexpr int kRThreads = SR_R_THREADS;   // 3 waves per SIMD; the register budget of 168 holds x in FP64 (78) + pipeline
 static constexpr int kRWaves = kRThreads / 64;
 static constexpr int kRBatch = SR_R_BATCH;       // dimensions per software-pipeline stage of the candidate evaluation
+#ifndef SR_R_EXP
+#define SR_R_EXP 0   // timing experiments only (tools/build_variant.py, profiles/r2_refine_decomposition.txt): 1 = main pass
+                     // alone (wrong scores), 5 = main pass without its LDS reads, 6 = main pass without its arithmetic
+#endif
+static constexpr uint32_t kRingEntries = 128;    // per (wave, level, state): < 64 pending + <= 64 appended per iteration
+static constexpr uint32_t kRingLists = 2 * 8 * kRingEntries;  // entries per wave: [level][state][128]
+static constexpr uint32_t kRingWave = 4 * kRingLists;         // u32 per wave: frame ids, remaining masks, best scores (f64)
+struct __attribute__((packed, aligned(4))) RowPiece { float v[4]; };  // 16 bytes of a feature row (rows are 4-byte aligned)
 
 template <int DT, int NS, int SPW>  // DT = compile-time feature dimension (0: run-time a.dim, features re-read from featsT)
 __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) {
@@ -302,87 +327,142 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
   for (int j = 0; j < SPW; j++) nd[j] = (uint32_t)j < ns ? a.n_dens_ps[s0 + j] : 0u;
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   __syncthreads();
+  if (f_begin >= f_end) return;  // (after the barrier: whole workgroup)
 
   uint32_t n_eval = 0;
-  for (uint64_t f = f_begin + tid; f < f_end; f += kRThreads) {
-    double x[DT ? DT : 1];
+  double x[DT ? DT : 1];
+  uint64_t fx = 0;  // frame whose features x[] / X() hold
+  bool fx_T = true; // (run-time dimension only) X() reads it from featsT / from the row-major buffer
+  // featsT through a buffer descriptor: address = base + 4 * f (VGPR) + 4 * k * ld (SGPR, stepped by scalar adds) -- one
+  // VGPR offset for all dimensions instead of 39 loop-invariant 64-bit row pointers that spill out of the SGPR file and
+  // come back through v_readlane.  (dim * ld * 4 < 2^32: the launcher checks.)
+  const __amdgpu_buffer_rsrc_t featsT_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.featsT), 0, (int)0xFFFFFFFFu, 0x00020000);
+  const uint32_t ld4 = (uint32_t)a.n_frames_ld * 4u;
+  auto load_x = [&](uint64_t f) __attribute__((always_inline)) {
+    fx = f; fx_T = true;
     if (DT) {
+      const uint32_t voff = (uint32_t)f * 4u;
 #pragma unroll
-      for (int k = 0; k < DT; k++) x[k] = (double)a.featsT[(uint64_t)k * a.n_frames_ld + f];
+      for (int k = 0; k < DT; k++)
+        x[DT ? k : 0] = (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(featsT_rsrc, voff, (uint32_t)k * ld4, 0));
     }
-    auto X = [&](uint32_t k) -> double { return DT ? x[DT ? k : 0] : (double)a.featsT[(uint64_t)k * a.n_frames_ld + f]; };
-    // score of the density whose plane column starts at LDS address `col0`, in density_score_sse's operation order
-    auto evaluate = [&](const unsigned char* col0) __attribute__((always_inline)) -> double {
-      // volatile: keeps every read a ds_read_b64 (256 B/clk, 64 banks); merged into ds_read2_b64 they would run at
-      // half rate on 32 banks, where densities d and d + 16 collide
-      const volatile __attribute__((address_space(3))) double* col =
-          (const volatile __attribute__((address_space(3))) double*)col0;  // col[plane * NS]
-      double l0 = 0.0, l1 = 0.0, dist, score;
-      if (DT) {
-        // software pipeline over batches of kRBatch dimensions: the reads of batch b+1 are issued before the
-        // arithmetic of batch b (volatile reads are not moved by the compiler, hence the explicit fences)
-        constexpr int NB_ = (DT + 1 + kRBatch - 1) / kRBatch;  // plane pairs 0..DT-1 = dimensions, pair DT = (norm, logw)
-        double pm[2][kRBatch], pv[2][kRBatch];
+  };
+  // the same from the row-major buffer: for the batches below, whose 64 lanes hold 64 unrelated frames -- a frame's
+  // features are 2 cache lines there against one line per dimension in featsT (measured: 11 ms of L2 traffic)
+  auto load_x_row = [&](uint64_t f) __attribute__((always_inline)) {
+    fx = f; fx_T = false;
+    if (DT) {
+      const float* xr = a.feats + f * (uint64_t)DT;
 #pragma unroll
-        for (int i = 0; i < kRBatch; i++)
-          if (i <= DT) { pm[0][i] = col[(2 * i) * NS]; pv[0][i] = col[(2 * i + 1) * NS]; }
+      for (int q = 0; q < DT / 4; q++) {
+        const RowPiece t = reinterpret_cast<const RowPiece*>(xr)[q];
 #pragma unroll
-        for (int b = 0; b < NB_; b++) {
-          const int cur = b & 1;
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int i = 0; i < kRBatch; i++) {
-            const int k = (b + 1) * kRBatch + i;
-            if (k <= DT) { pm[cur ^ 1][i] = col[(2 * k) * NS]; pv[cur ^ 1][i] = col[(2 * k + 1) * NS]; }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int i = 0; i < kRBatch; i++) {
-            const int k = b * kRBatch + i;
-            if (k < (int)(DT - (DT & 1))) {
-              double u = x[DT ? k : 0] - pm[cur][i];
-              u = u * u;
-              u = u * pv[cur][i];
-              if (k & 1) l1 = l1 + u; else l0 = l0 + u;
-            } else if (k == DT - 1) {  // odd dimension count: scalar tail (Mixtures.cpp:680-683)
-              dist = l0 + l1;
-              const double t = x[DT ? k : 0] - pm[cur][i];
-              dist += t * t * pv[cur][i];
-            } else if (k == DT) {
-              if (!(DT & 1)) dist = l0 + l1;
-              score = pm[cur][i] + dist / 2;
-              score -= pv[cur][i];
-            }
-          }
-          // pins this batch's arithmetic between the read groups (ordered against the volatile reads); without it
-          // the arithmetic sinks below all 80 reads and their 160 destination registers spill
-          asm volatile("" : "+v"(l0), "+v"(l1));
-        }
-      } else {
-        for (uint32_t k = 0; k < D2; k += 2) {
-          double u = X(k) - col[(2 * k) * NS];
-          u = u * u;
-          u = u * col[(2 * k + 1) * NS];
-          l0 = l0 + u;
-          double v = X(k + 1) - col[(2 * k + 2) * NS];
-          v = v * v;
-          v = v * col[(2 * k + 3) * NS];
-          l1 = l1 + v;
-        }
-        dist = l0 + l1;
-        if (D & 1u) {
-          const double t = X(D - 1) - col[(2 * (D - 1)) * NS];
-          dist += t * t * col[(2 * (D - 1) + 1) * NS];
-        }
-        score = col[(2 * D) * NS] + dist / 2;
-        score -= col[(2 * D + 1) * NS];
+        for (int i = 0; i < 4; i++) x[DT ? 4 * q + i : 0] = (double)t.v[i];
       }
-      return score;
-    };
+#pragma unroll
+      for (int k = DT - DT % 4; k < DT; k++) x[DT ? k : 0] = (double)xr[k];
+    }
+  };
+  auto X = [&](uint32_t k) -> double {
+    return DT ? x[DT ? k : 0] : (double)(fx_T ? a.featsT[(uint64_t)k * a.n_frames_ld + fx] : a.feats[fx * D + k]);
+  };
+  // score of the density whose plane column starts at LDS address `col0`, in density_score_sse's operation order
+  auto evaluate = [&](const unsigned char* col0) __attribute__((always_inline)) -> double {
+    // volatile: keeps every read a ds_read_b64 (256 B/clk, 64 banks); merged into ds_read2_b64 they would run at
+    // half rate on 32 banks, where densities d and d + 16 collide
+    const volatile __attribute__((address_space(3))) double* col =
+        (const volatile __attribute__((address_space(3))) double*)col0;  // col[plane * NS]
+    double l0 = 0.0, l1 = 0.0, dist, score;
+    if (DT) {
+      // software pipeline over batches of kRBatch dimensions: the reads of batch b+1 are issued before the
+      // arithmetic of batch b (volatile reads are not moved by the compiler, hence the explicit fences)
+      constexpr int NB_ = (DT + 1 + kRBatch - 1) / kRBatch;  // plane pairs 0..DT-1 = dimensions, pair DT = (norm, logw)
+      double pm[2][kRBatch], pv[2][kRBatch];
+#pragma unroll
+      for (int i = 0; i < kRBatch; i++)
+        if (i <= DT) {
+          if (SR_R_EXP == 5) { pm[0][i] = x[DT ? (i + 1) % DT : 0]; pv[0][i] = x[DT ? (i + 2) % DT : 0]; }
+          else { pm[0][i] = col[(2 * i) * NS]; pv[0][i] = col[(2 * i + 1) * NS]; }
+        }
+#pragma unroll
+      for (int b = 0; b < NB_; b++) {
+        const int cur = b & 1;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < kRBatch; i++) {
+          const int k = (b + 1) * kRBatch + i;
+          if (k <= DT) {
+            if (SR_R_EXP == 5) { pm[cur ^ 1][i] = x[DT ? (k + 1) % DT : 0]; pv[cur ^ 1][i] = x[DT ? (k + 2) % DT : 0]; }
+            else { pm[cur ^ 1][i] = col[(2 * k) * NS]; pv[cur ^ 1][i] = col[(2 * k + 1) * NS]; }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < kRBatch; i++) {
+          const int k = b * kRBatch + i;
+          if (SR_R_EXP == 6) { asm volatile("" :: "v"(pm[cur][i]), "v"(pv[cur][i])); if (k == DT) score = pm[cur][i]; continue; }
+          if (k < (int)(DT - (DT & 1))) {
+            double u = x[DT ? k : 0] - pm[cur][i];
+            u = u * u;
+            u = u * pv[cur][i];
+            if (k & 1) l1 = l1 + u; else l0 = l0 + u;
+          } else if (k == DT - 1) {  // odd dimension count: scalar tail (Mixtures.cpp:680-683)
+            dist = l0 + l1;
+            const double t = x[DT ? k : 0] - pm[cur][i];
+            dist += t * t * pv[cur][i];
+          } else if (k == DT) {
+            if (!(DT & 1)) dist = l0 + l1;
+            score = pm[cur][i] + dist / 2;
+            score -= pv[cur][i];
+          }
+        }
+        // pins this batch's arithmetic between the read groups (ordered against the volatile reads); without it
+        // the arithmetic sinks below all 80 reads and their 160 destination registers spill
+        asm volatile("" : "+v"(l0), "+v"(l1));
+      }
+    } else {
+      for (uint32_t k = 0; k < D2; k += 2) {
+        double u = X(k) - col[(2 * k) * NS];
+        u = u * u;
+        u = u * col[(2 * k + 1) * NS];
+        l0 = l0 + u;
+        double v = X(k + 1) - col[(2 * k + 2) * NS];
+        v = v * v;
+        v = v * col[(2 * k + 3) * NS];
+        l1 = l1 + v;
+      }
+      dist = l0 + l1;
+      if (D & 1u) {
+        const double t = X(D - 1) - col[(2 * (D - 1)) * NS];
+        dist += t * t * col[(2 * (D - 1) + 1) * NS];
+      }
+      score = col[(2 * D) * NS] + dist / 2;
+      score -= col[(2 * D + 1) * NS];
+    }
+    return score;
+  };
 
-    // Phase 1: the first candidate of every state -- one evaluation per state in every lane, no divergence.
+  // ---- wave-private candidate lists (global memory, a few KB per wave: L1/L2 resident) -----------------------------
+  // an entry = (frame, candidates still to evaluate, best score so far): the batches need no look-up in the mask array or
+  // the score table, they only store to the table where a later candidate wins
+  uint32_t* ring = a.ring + ((uint64_t)(blockIdx.y * gridDim.x + blockIdx.x) * kRWaves + wave) * kRingWave;
+  uint32_t* ring_mk = ring + kRingLists;
+  double* ring_sc = reinterpret_cast<double*>(ring + 2 * kRingLists);
+  uint64_t cnt1 = 0, cnt2 = 0;  // eight 8-bit counters each (wave-uniform): frames pending per state, level 1 / level 2
+  const uint64_t f_wave = f_begin + (uint64_t)wave * 64;
+  auto frame_of = [&](uint32_t lf) -> uint64_t { return f_wave + (uint64_t)(lf >> 6) * kRThreads + (lf & 63u); };
+  const uint32_t chunk_shift = a.chunks == 1 ? 0u : a.chunks == 2 ? 1u : 2u;
+
+  const uint32_t n_it = (uint32_t)((f_end - f_begin + kRThreads - 1) / kRThreads);
+  for (uint32_t it = 0; it < n_it; it++) {
+    const uint64_t fr = f_wave + (uint64_t)it * kRThreads + lane;
+    const bool valid = fr < f_end;
+    const uint64_t f = valid ? fr : f_end - 1;  // lanes past the end shadow the last frame; they store and append nothing
+    const uint32_t lf = it * 64u + (uint32_t)lane;
+    load_x(f);
+    // main pass: the first candidate of every state -- one evaluation per state in every lane, no divergence
     double res[SPW];
-    uint32_t rem[SPW];  // candidates left after the first
 #pragma unroll
     for (int h = 0; h < SPW / 4; h++) {
       const uint4 v = reinterpret_cast<const uint4*>(a.mask)[(uint64_t)((s0 >> 2) + h) * a.n_frames + f];
@@ -393,65 +473,128 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
         const uint32_t n = nd[j];
         uint32_t mask = mk[jj];
         mask &= n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);  // padding slots of the prefilter are not densities
-        n_eval += __builtin_popcount(mask);
         res[j] = 1e10;  // min_score seed (Mixtures.cpp:699)
-        if (mask) {     // (empty only for a state without densities)
-          const double score = evaluate(panel_raw + (size_t)j * state_bytes + ((__builtin_ctz(mask) + s0 + j) & (NS - 1)) * 8u);
-          if (score < res[j]) res[j] = score;
+        if (n) {        // wave-uniform (a state without densities has an empty mask and keeps the seed)
+          const double score = evaluate(panel_raw + (size_t)j * state_bytes + ((__builtin_ctz(mask | 0x80000000u) + s0 + j) & (NS - 1)) * 8u);
+          if (mask != 0 && score < res[j]) res[j] = score;
+          n_eval += (valid && mask != 0) ? 1u : 0u;
         }
-        rem[j] = mask & (mask - 1);
+        const bool more = valid && (mask & (mask - 1)) != 0;
+        const uint64_t b = (SR_R_EXP == 1 || SR_R_EXP >= 5) ? 0 : __ballot(more);
+        if (b) {  // wave-uniform
+          const uint32_t c1 = (uint32_t)(cnt1 >> (8 * j)) & 0xFFu;
+          const uint32_t pos = c1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+          if (more) {
+            ring[(uint32_t)j * kRingEntries + pos] = lf;
+            ring_mk[(uint32_t)j * kRingEntries + pos] = mask & (mask - 1);
+            ring_sc[(uint32_t)j * kRingEntries + pos] = res[j];
+          }
+          cnt1 += (uint64_t)__builtin_popcountll(b) << (8 * j);
+        }
       }
-    }
-    // Phase 2: the few lanes that have further candidates (about 1 % of the (frame, state) pairs) work them off
-    // together, each on its own (state, density); different states' planes keep the bank pair d mod 32.  The minimum
-    // does not depend on the order (strict <, NaN never wins: as in the reference's ascending scan).
-    for (;;) {
-      uint32_t any = 0;
-#pragma unroll
-      for (int j = 0; j < SPW; j++) any |= rem[j];
-      if (!any) break;
-      int jsel = 0;
-      uint32_t msel = 0;
-#pragma unroll
-      for (int j = SPW - 1; j >= 0; j--)
-        if (rem[j]) { jsel = j; msel = rem[j]; }
-      const uint32_t d = __builtin_ctz(msel);
-#pragma unroll
-      for (int j = 0; j < SPW; j++)
-        if (j == jsel) rem[j] = msel & (msel - 1);
-      const double score = evaluate(panel_raw + (size_t)jsel * state_bytes + ((d + s0 + jsel) & (NS - 1)) * 8u);
-#pragma unroll
-      for (int j = 0; j < SPW; j++)
-        if (j == jsel && score < res[j]) res[j] = score;
     }
     // a mixture of more than 32 densities spans `chunks` consecutive pseudo-states: fold their minima (NaN never
     // wins, as in the reference's scan)
-    if (a.chunks == 1) {
-      double* o = a.out + f * a.ld + s0;
-      if (ns == SPW) {  // ld is a multiple of 8: 64-byte (32-byte for SPW = 4) aligned pieces
+    if (valid) {
+      if (a.chunks == 1) {
+        double* o = a.out + f * a.ld + s0;
+        if (ns == SPW) {  // ld is a multiple of 8: 64-byte (32-byte for SPW = 4) aligned pieces
 #pragma unroll
-        for (int j = 0; j < SPW; j += 2) *reinterpret_cast<double2*>(o + j) = make_double2(res[j], res[j + 1]);
-      } else {
+          for (int j = 0; j < SPW; j += 2) *reinterpret_cast<double2*>(o + j) = make_double2(res[j], res[j + 1]);
+        } else {
 #pragma unroll
-        for (int j = 0; j < SPW; j++)
-          if ((uint32_t)j < ns) o[j] = res[j];
+          for (int j = 0; j < SPW; j++)
+            if ((uint32_t)j < ns) o[j] = res[j];
+        }
+      } else if (a.chunks == 2) {
+        double* o = a.out + f * a.ld + s0 / 2;
+#pragma unroll
+        for (int j = 0; j < SPW; j += 2) {
+          const double m = res[j + 1] < res[j] ? res[j + 1] : res[j];
+          if ((uint32_t)j < ns) o[j / 2] = m;
+        }
+      } else {  // 4
+        double* o = a.out + f * a.ld + s0 / 4;
+#pragma unroll
+        for (int j = 0; j < SPW; j += 4) {
+          double m = res[j + 1] < res[j] ? res[j + 1] : res[j];
+          m = res[j + 2] < m ? res[j + 2] : m;
+          m = res[j + 3] < m ? res[j + 3] : m;
+          if ((uint32_t)j < ns) o[j / 4] = m;
+        }
       }
-    } else if (a.chunks == 2) {
-      double* o = a.out + f * a.ld + s0 / 2;
-#pragma unroll
-      for (int j = 0; j < SPW; j += 2) {
-        const double m = res[j + 1] < res[j] ? res[j + 1] : res[j];
-        if ((uint32_t)j < ns) o[j / 2] = m;
+    }
+    // ---- work off the lists: every list is kept below 64 pending frames (one more iteration's appends must fit);
+    // after the last iteration they are emptied.  One batch = <= 64 pairs of ONE state j (wave-uniform level, j, n):
+    // level 1 evaluates each pair's second candidate, level 2 everything after the second.
+    const bool last = it + 1 == n_it;
+    // table stores issued after the last list store (wave-uniform): SPW/2 row pieces, unless the data-dependent paths ran
+    uint32_t tail_stores = (!chunk_shift && ns == SPW && __any(valid)) ? (uint32_t)(SPW / 2) : 0u;
+    for (;;) {
+      uint32_t level, j, n;
+      {
+        const uint64_t full1 = cnt1 & 0x4040404040404040ull, full2 = cnt2 & 0x4040404040404040ull;
+        // a full level-2 list first (level 1 appends to it), then a full level-1 list; at the end whatever is left
+        const uint64_t pick2 = full2 ? full2 : (last && !full1 && !cnt1) ? cnt2 : 0;
+        const uint64_t pick1 = full2 ? 0 : full1 ? full1 : last ? cnt1 : 0;
+        const uint64_t pick = pick1 ? pick1 : pick2;
+        if (!pick) break;
+        level = pick1 ? 1u : 2u;
+        j = (uint32_t)__builtin_ctzll(pick) >> 3;
+        const uint32_t have_ = (uint32_t)((pick1 ? cnt1 : cnt2) >> (8u * j)) & 0xFFu;
+        n = have_ < 64u ? have_ : 64u;
       }
-    } else {  // 4
-      double* o = a.out + f * a.ld + s0 / 4;
-#pragma unroll
-      for (int j = 0; j < SPW; j += 4) {
-        double m = res[j + 1] < res[j] ? res[j + 1] : res[j];
-        m = res[j + 2] < m ? res[j + 2] : m;
-        m = res[j + 3] < m ? res[j + 3] : m;
-        if ((uint32_t)j < ns) o[j / 4] = m;
+      // opaque to the optimiser from here on: ONE copy of the batch code, whatever path selected it (threading the
+      // selection through duplicated the evaluation 20 times and the kernel no longer fitted the instruction cache)
+      asm volatile("" : "+s"(level), "+s"(j), "+s"(n));
+      const bool l1 = level == 1;
+      const uint32_t have = (uint32_t)((l1 ? cnt1 : cnt2) >> (8u * j)) & 0xFFu;
+      const uint32_t slot0 = ((level - 1u) * 8u + j) * kRingEntries;
+      if (l1) cnt1 -= (uint64_t)n << (8u * j); else cnt2 -= (uint64_t)n << (8u * j);
+      const bool live = (uint32_t)lane < n;
+      // This wave's earlier list stores must have landed before they are read back.  Stores complete in issue order,
+      // and the youngest ones are always table stores nobody reads here (the main pass' row pieces, SPW/2 of them when
+      // the workgroup owns SPW whole states; a previous batch's single update): waiting for all but those skips their
+      // HBM round trip.  Mixtures of more than 32 densities read the table below and wait for everything.
+      if (tail_stores == (uint32_t)(SPW / 2)) __builtin_amdgcn_s_waitcnt(0x0F70 | (SPW / 2));  // vmcnt(SPW/2)
+      else if (tail_stores == 1u) __builtin_amdgcn_s_waitcnt(0x0F71);                          // vmcnt(1)
+      else __builtin_amdgcn_s_waitcnt(0x0F70);                                                  // vmcnt(0)
+      asm volatile("" ::: "memory");
+      const uint32_t at = slot0 + have - n + (live ? (uint32_t)lane : 0u);
+      const uint32_t lfb = ring[at];
+      uint32_t m = live ? ring_mk[at] : 0u;
+      double cur = ring_sc[at];
+      const uint64_t fb = frame_of(lfb);
+      load_x_row(fb);
+      double* o = a.out + fb * a.ld + ((s0 + j) >> chunk_shift);
+      // a mixture of more than 32 densities: the table entry is shared by the state's pseudo-states and may have been
+      // lowered through another one since -- take it from the table (this wave's own stores have landed, see above)
+      if (chunk_shift) cur = *o;
+      const double before = cur;
+      const unsigned char* panel = panel_raw + (size_t)j * state_bytes;
+      do {  // level 1: exactly one round (every live lane has a second candidate); level 2: until every lane is done
+        const double score = evaluate(panel + ((__builtin_ctz(m | 0x80000000u) + s0 + j) & (NS - 1)) * 8u);
+        if (m != 0) { n_eval++; if (score < cur) cur = score; }
+        m &= m - 1;
+      } while (!l1 && __any(m != 0));
+      if (l1) {
+        const uint64_t b = __ballot(m != 0);
+        if (b) {  // wave-uniform: pairs with a third candidate move on to level 2
+          const uint32_t c2 = (uint32_t)(cnt2 >> (8u * j)) & 0xFFu;
+          const uint32_t pos = c2 + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+          if (m != 0) {
+            ring[(8u + j) * kRingEntries + pos] = lfb;
+            ring_mk[(8u + j) * kRingEntries + pos] = m;
+            ring_sc[(8u + j) * kRingEntries + pos] = cur;
+          }
+          cnt2 += (uint64_t)__builtin_popcountll(b) << (8u * j);
+        }
       }
+      // the table update comes last: it is the one store the next batch need not wait for
+      asm volatile("" ::: "memory");
+      const bool lower = live && cur < before;
+      tail_stores = (!chunk_shift && __any(lower)) ? 1u : 0u;
+      if (lower) *o = cur;
     }
   }
   if (a.n_refined) {
@@ -486,18 +629,34 @@ hipError_t launch_transpose_feats(const float* feats, uint64_t n_frames, uint32_
 
 int gmm_refine_slots(uint32_t max_dens) { return max_dens <= 8 ? 8 : max_dens <= 16 ? 16 : 32; }
 
+static void refine_grid(const GmmRefineArgs& a, int spw, uint32_t* n_sgroups, uint64_t* splits, uint64_t* frames_per_split) {
+  *n_sgroups = (a.n_pstates + spw - 1) / spw;
+  // two rounds of workgroups over the 256 CUs at least (one workgroup per CU when it takes the whole LDS), without
+  // cutting the frame range below one pass of the threads
+  uint64_t sp = std::max<uint64_t>(1, (512 + *n_sgroups - 1) / *n_sgroups);
+  sp = std::min<uint64_t>(sp, (a.n_frames + kRThreads - 1) / kRThreads);
+  sp = std::max<uint64_t>(sp, 1);
+  *frames_per_split = (a.n_frames + sp - 1) / sp;
+  *splits = *frames_per_split ? (a.n_frames + *frames_per_split - 1) / *frames_per_split : 1;
+}
+static int refine_spw(const GmmRefineArgs& a) {
+  // 8 states per workgroup when their parameters fit the 160 KiB of LDS (dim <= 39 at 32 slots), else 4
+  return (a.n_slots < 32 || (size_t)(2 * a.dim + 2) * a.n_slots * 8 * 8 <= 160 * 1024) ? 8 : 4;
+}
+size_t gmm_refine_ring_words(const GmmRefineArgs& a) {
+  uint32_t g; uint64_t sp, fps;
+  refine_grid(a, refine_spw(a), &g, &sp, &fps);
+  return (size_t)g * sp * kRWaves * kRingWave;
+}
+
 template <int NS, int SPW>
 static hipError_t launch_refine_ns(const GmmRefineArgs& a0, hipStream_t stream) {
   GmmRefineArgs a = a0;
   const size_t state_bytes = (size_t)(2 * a.dim + 2) * NS * 8;
   const size_t smem = (SPW * state_bytes + 1023) & ~(size_t)1023;
-  const uint32_t n_sgroups = (a.n_pstates + SPW - 1) / SPW;
-  // two rounds of workgroups over the 256 CUs at least (one workgroup per CU when it takes the whole LDS), without
-  // cutting the frame range below one pass of the threads
-  uint64_t splits = std::max<uint64_t>(1, (512 + n_sgroups - 1) / n_sgroups);
-  splits = std::min<uint64_t>(splits, (a.n_frames + kRThreads - 1) / kRThreads);
-  a.frames_per_split = (a.n_frames + splits - 1) / splits;
-  splits = (a.n_frames + a.frames_per_split - 1) / a.frames_per_split;
+  uint32_t n_sgroups;
+  uint64_t splits;
+  refine_grid(a, SPW, &n_sgroups, &splits, &a.frames_per_split);
   const dim3 grid(n_sgroups, (unsigned)splits), block(kRThreads);
   auto go = [&](auto kernel) {
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -514,8 +673,8 @@ static hipError_t launch_refine_ns(const GmmRefineArgs& a0, hipStream_t stream) 
 
 hipError_t launch_gmm_refine(const GmmRefineArgs& a, hipStream_t stream) {
   if (a.n_frames == 0) return hipSuccess;
-  // 8 states per workgroup when their parameters fit the 160 KiB of LDS (dim <= 39 at 32 slots), else 4
-  const bool eight = (size_t)(2 * a.dim + 2) * a.n_slots * 8 * 8 <= 160 * 1024;
+  if (!a.ring || (uint64_t)a.dim * a.n_frames_ld * 4u >= (1ull << 32)) return hipErrorInvalidValue;  // (buffer offsets are 32 bit)
+  const bool eight = refine_spw(a) == 8;
   switch (a.n_slots) {
     case 8: return launch_refine_ns<8, 8>(a, stream);
     case 16: return launch_refine_ns<16, 8>(a, stream);

@@ -66,7 +66,8 @@ struct GmmPrefilterArgs {
   uint32_t chunks;              // 1, 2 or 4 consecutive state slots (of 32 densities) make up one state
 };
 struct GmmRefineArgs {
-  const float* featsT;          // [dim x n_frames_ld] transposed features
+  const float* feats;           // [n_frames x dim] row-major features (batches of unrelated frames)
+  const float* featsT;          // [dim x n_frames_ld] transposed features (main pass: 64 consecutive frames per wave)
   uint64_t n_frames, n_frames_ld;
   uint32_t dim, n_pstates, chunks;  // pseudo-states = states x chunks (a state of up to 32*chunks densities)
   const uint32_t* n_dens_ps;    // [n_pstates] densities in each pseudo-state (0..32)
@@ -77,7 +78,9 @@ struct GmmRefineArgs {
   double* out; uint32_t ld;
   uint64_t frames_per_split;    // set by the launcher
   unsigned long long* n_refined;  // optional: += densities evaluated (profiling)
+  uint32_t* ring;               // workspace, gmm_refine_ring_words() u32: wave-private lists of pairs with further candidates
 };
+size_t gmm_refine_ring_words(const GmmRefineArgs& a);  // needs n_frames, n_pstates, dim, n_slots
 hipError_t launch_gmm_prefilter(const GmmPrefilterArgs& a, int ks32, hipStream_t stream);
 int gmm_prefilter_frames_per_tile();
 // does the fp16 MFMA keep subnormal inputs on this device / in this build (an assumption of the prefilter's error bound)?

@@ -106,7 +106,7 @@ struct sr_model {
   uint32_t pf_groups = 0, pf_ny = 0, max_dens = 0, pf_slots = 0, pf_chunks = 1, pf_pstates = 0;
   DevBuf<unsigned char> pf_apack;
   DevBuf<float> pf_anorm, featsT;
-  DevBuf<uint32_t> pf_split, pf_mask, pf_ndens;
+  DevBuf<uint32_t> pf_split, pf_mask, pf_ndens, pf_ring;
   DevBuf<double> pf_rows;
   DevBuf<unsigned long long> pf_counter;
   // streams / workspace
@@ -479,10 +479,12 @@ int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm
     pa.apack = m->pf_apack.p; pa.grp_anorm = m->pf_anorm.p; pa.split_begin = m->pf_split.p;
     pa.mask = m->pf_mask.p; pa.nx = nx; pa.ny = m->pf_ny; pa.chunks = m->pf_chunks;
     GmmRefineArgs ra{};
-    ra.featsT = m->featsT.p; ra.n_frames = n_frames; ra.n_frames_ld = ldT; ra.dim = m->dim; ra.n_pstates = m->pf_pstates; ra.chunks = m->pf_chunks;
+    ra.feats = d_feats; ra.featsT = m->featsT.p; ra.n_frames = n_frames; ra.n_frames_ld = ldT; ra.dim = m->dim; ra.n_pstates = m->pf_pstates; ra.chunks = m->pf_chunks;
     ra.n_dens_ps = m->pf_ndens.p; ra.rows = m->pf_rows.p; ra.n_slots = m->pf_slots;
     ra.mask = m->pf_mask.p; ra.out = d_out; ra.ld = m->ld;
     ra.n_refined = m->profiling ? m->pf_counter.p : nullptr;
+    HIP_TRY(m->pf_ring.ensure(gmm_refine_ring_words(ra)));
+    ra.ring = m->pf_ring.p;
     if (m->profiling) m->prof.refined_pairs += n_frames * (uint64_t)m->n_states;
     EventPair ep_p{}, ep_r{};
     if ((rc = prof_begin(m, m->s_gmm, 0, &ep))) return rc;
@@ -633,6 +635,8 @@ int sr_model_create(int device, uint32_t dim, uint32_t n_states, const uint32_t*
   // MI355X has 288 GB of HBM to spend.
   const size_t chunk_bytes = (env ? (size_t)atol(env) : 16384) << 20;
   m->chunk_frames = std::max<size_t>(1, chunk_bytes / ((size_t)m->ld * sizeof(double)));
+  // the refinement kernel addresses the transposed feature copy of a chunk with 32-bit buffer offsets
+  m->chunk_frames = std::min<size_t>(m->chunk_frames, ((size_t)1 << 32) / (4 * (size_t)dim) - 128);
   if (const char* ov = getenv("SRGPU_OVERLAP")) m->overlap = atoi(ov) != 0;
   *out = own.release();
   return SR_OK;

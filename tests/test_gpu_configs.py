@@ -81,6 +81,10 @@ def test_cfg5_bigram_at_size_vs_restatement(tmp_path, oracle_lib):
         want.append(oracle_lib.bigram_decode(dense, word_off, mixtures, lex.silence_idx, lm, tdp, 200.0, capi.FLT_MAX))
     o.close()
     feats100, off100 = synth.make_batch(100, 30, 60, 39, seed=34)
+    for u in range(0, 100, 4):  # every fourth utterance drawn from the model: several words in its traceback
+        x = synth.sample_utterance(spec, lex, rng.integers(1, lex.n_words, size=5), seed=200 + u, frames_per_state=(2, 4))
+        n = min(len(x), int(off100[u + 1] - off100[u]))
+        feats100[int(off100[u]):int(off100[u]) + n] = x[:n]
     with capi.Model.from_mixset(mp, 39) as m:
         bg = m.bigram(word_off, mixtures, lex.silence_idx, lm, tdp)
         corpus = m.upload(np.concatenate(utts), off)
@@ -118,7 +122,7 @@ def test_cfg5_bigram_at_size_vs_restatement(tmp_path, oracle_lib):
         del os.environ["SRGPU_SCORE_CHUNK_MB"]
     assert np.array_equal(w1, w3) and np.array_equal(t1, t3) and np.array_equal(o1, o3)
     assert np.array_equal(s1.view(np.uint32), s3.view(np.uint32))
-    assert int(o1[-1]) > 100
+    assert int(o1[-1]) > 100  # (a random-feature utterance ends in one item, a sampled one in several)
     for k, u in enumerate(perm):
         a, b, a2, b2 = int(o1[u]), int(o1[u + 1]), int(o2[k]), int(o2[k + 1])
         assert np.array_equal(w1[a:b], w2[a2:b2]) and np.array_equal(t1[a:b], t2[a2:b2]), u

@@ -14,7 +14,7 @@ out_dir = os.path.join(B.CSRC, "build", "variants", name)
 os.makedirs(out_dir, exist_ok=True)
 objs = []
 procs = []
-for src in B.SOURCES:
+for src in [x for x in B.SOURCES if os.path.exists(os.path.join(B.CSRC, x))]:
     obj = os.path.join(out_dir, src + ".o")
     objs.append(obj)
     cmd = ["hipcc", "-x", "hip", "-c", os.path.join(B.CSRC, src), "-o", obj] + B.FLAGS + B.PER_FILE.get(src, []) + defs
