@@ -196,6 +196,10 @@ SR_API int sr_recognize_bigram_corpus(sr_model* m, sr_corpus* c, sr_bigram* b, c
 /* Diagnostic: does the fp16 matrix pipe keep subnormal inputs on this device (an assumption of SR_GMM_PREFILTER's
  * error bound; when it does not hold, models are scored by SR_GMM_EXACT's kernel instead)? */
 SR_API int sr_probe_fp16_denormals(int device, int* preserved);
+/* ... and does its fp32 accumulation stay inside the bound's model?  Adversarial 96-term fp16 dot products with known exact
+ * sums through the prefilter's own MFMA chain: within_model = 1 iff every |error| <= 87 * 2^-24 * sum |a_k b_k|;
+ * worst_ratio (may be NULL) = the largest |error| / (2^-24 * sum |a_k b_k|) seen.  Both probes run at model creation. */
+SR_API int sr_probe_fp16_accumulation(int device, int* within_model, double* worst_ratio);
 
 /* ---- measurement --------------------------------------------------------------------------------
  * When enabled, every kernel launch of this model handle is bracketed by HIP events on the

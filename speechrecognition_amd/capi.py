@@ -25,7 +25,7 @@ SYMBOLS = [
     "sr_corpus_upload", "sr_corpus_destroy", "sr_score_corpus", "sr_score_frames", "sr_lexicon_create",
     "sr_lexicon_destroy", "sr_recognize_corpus", "sr_recognize_batch", "sr_align_corpus", "sr_align_corpus_pruned", "sr_path_scores_corpus", "sr_model_create_from_statistics", "sr_mixset_write", "sr_model_set_tying", "sr_model_tying_info", "sr_accumulate_corpus",
     "sr_bigram_create", "sr_bigram_destroy", "sr_recognize_bigram_corpus",
-    "sr_probe_fp16_denormals",
+    "sr_probe_fp16_denormals", "sr_probe_fp16_accumulation",
     "sr_profile_enable", "sr_profile_reset", "sr_profile_read",
 ]
 
@@ -88,6 +88,7 @@ def lib():
         L.sr_bigram_destroy.argtypes = [vp]
         L.sr_recognize_bigram_corpus.argtypes = [vp, vp, vp, C.POINTER(BigramParams), vp, vp, vp, vp]
         L.sr_probe_fp16_denormals.argtypes = [i32, C.POINTER(i32)]
+        L.sr_probe_fp16_accumulation.argtypes = [i32, C.POINTER(i32), C.POINTER(dbl)]
         L.sr_profile_enable.argtypes = [vp, i32]
         L.sr_profile_reset.argtypes = [vp]
         L.sr_profile_read.argtypes = [vp, C.POINTER(Profile)]

@@ -12,9 +12,17 @@
 //   fp16 values are exact in fp32; <= 81 + 3 fp32 additions, each off by 2^-24 of a partial sum that never exceeds
 //   |konst| + sum |a b| (first order):
 //   |approx - exact| <= (2^-10 (1 + 2^-12) + 87 * 2^-24) |a||b| + 87 * 2^-24 |konst| + 2^-25 (|b|_1 / sA + |a|_1) (1 + 2^-11)
-// -> eps = kKappa16 |a||b| + kKonst16 |konst| + kAbs16 (|b| / sA + |a|),  kKappa16 = 1.05e-3 (needed 9.82e-4),
-//    kKonst16 = 1e-5 (5.2e-6), kAbs16 = 3.1e-8 * sqrt(2 * 46) (|v|_1 <= sqrt(K) |v|_2, needed 2.98e-8 * sqrt(K));
-//    |a|, |konst| = the largest over the state's densities, rounded up on the host; |b| per frame, rounded up.
+// -> eps = kKappa16 |a||b| + kKonst16 |konst| + kAbs16 (|b| / sA + |a|),  kKappa16 = 1.05e-3 (needed 9.82e-4: the
+//    operand roundings are round-to-nearest by construction -- v_cvt_f16_f32 here, float -> _Float16 on the host, whose
+//    double rounding adds 2^-13 relative to the 2^-11 -- so only the 87 * 2^-24 part rests on the hardware),
+//    kKonst16 = 1.1e-5 (needed 5.19e-6 = 87 * 2^-24: x2, so that an accumulator that TRUNCATED every addition, 2^-23
+//    each, would still be inside), kAbs16 = 6.0e-7 (needed 2^-25 (1 + 2^-11) sqrt(K) = 2.92e-7 at the padded K = 96,
+//    |v|_1 <= sqrt(K) |v|_2: x2);  |a|, |konst| = the largest over the state's densities, rounded up on the host;
+//    |b| per frame, rounded up.
+// The accumulation model itself (<= 2^-24 of the running magnitude per addition, whatever the order inside the
+// instruction) is probed on the device the model is created on, next to the subnormal probe: probe_fp16_accumulation()
+// runs adversarial 96-term dot products with known exact sums through the same three-instruction MFMA chain and
+// requires |error| <= 87 * 2^-24 * sum |a_k b_k|; a device that fails is scored by the exact kernel instead.
 // Every density whose approximation lies within 2*eps of the state's smallest approximation -- plus anything that is
 // not a number -- is a candidate; the true arg-min is provably among them.  A feature beyond fp16's range
 // (|x| > 255) turns its frame's scores into inf/NaN: every density stays a candidate.  P writes one 32-bit candidate
@@ -33,6 +41,8 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cmath>
+#include <vector>
 
 #include "kernels.h"
 
@@ -55,7 +65,7 @@ static constexpr int kGroupBlocks = 8;     // every 4-state group is padded to 8
 // stage first, so that the pipeline runs across stage boundaries and the LDS-DMA of stage s+2 goes into the buffer
 // everybody has just finished reading.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-static constexpr float kKappa16 = 1.05e-3f, kKonst16 = 1.0e-5f, kAbs16 = 3.0e-7f;
+static constexpr float kKappa16 = 1.05e-3f, kKonst16 = 1.1e-5f, kAbs16 = 6.0e-7f;
 
 __device__ inline uint32_t pack_f16x2(float lo, float hi) {
   const _Float16 l = (_Float16)lo, h = (_Float16)hi;
@@ -240,6 +250,105 @@ hipError_t probe_fp16_denormals(hipStream_t stream, bool* preserved) {
   if (e != hipSuccess) return e;
   *preserved = true;
   for (int i = 0; i < 64; i++) *preserved = *preserved && h[i] == 9.765625e-4f;
+  return hipSuccess;
+}
+
+// ---- accumulation probe ------------------------------------------------------------------------------------------
+// One 16x16 tile through the kernel's own MFMA chain (three k-steps of 32, accumulator from zero): A[16][96] and B[96][16]
+// fp16 from global memory, D[16][16] fp32 back.  The host builds the operands (below) and knows every exact sum.
+__global__ void fp16_accumulation_probe_kernel(const _Float16* A, const _Float16* B, float* out) {
+  const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+  v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 3; ks++) {
+    f16x8 a, b;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int k = 32 * ks + 8 * q + j;
+      a[j] = A[r * 96 + k];   // A operand: row = lane & 15, k = 32 ks + 8 (lane >> 4) + j
+      b[j] = B[k * 16 + r];   // B operand: column = lane & 15, same k
+    }
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) out[(4 * q + i) * 16 + r] = acc[i];  // C/D: column = lane & 15, row = 4 (lane >> 4) + reg
+}
+
+// Adversarial operand sets, all products exact in fp32 (11 x 11 significant bits) and all exact sums exact in double:
+//   family 0  one product of 2^23 and 95 products of 0.75: every addition to the big term is a tie-or-worse rounding
+//             (a truncating accumulator ends about 50 units low, the model allows 43)
+//   family 1  cancellation: 47 pairs +-(2^10 + d_k) with different small d_k, residue ~ 2^-4 .. 2^2 against sum |p| ~ 1e5
+//   family 2  96 equal products (1 + 2^-10)^2: a short internal accumulator or a wrong k order shows at once
+//   family 3  random signs and magnitudes over 12 binades
+// worst_ratio (optional) receives max |error| / (2^-24 sum |p|) -- the model allows 87.
+hipError_t probe_fp16_accumulation(hipStream_t stream, bool* ok, double* worst_ratio) {
+  const int kCases = 8;  // 8 tiles of 16 x 16 dot products
+  std::vector<_Float16> hA((size_t)kCases * 16 * 96), hB((size_t)kCases * 96 * 16);
+  uint64_t rng = 0x9E3779B97F4A7C15ull;
+  auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+  for (int t = 0; t < kCases; t++) {
+    _Float16* A = hA.data() + (size_t)t * 16 * 96;
+    _Float16* B = hB.data() + (size_t)t * 96 * 16;
+    for (int k = 0; k < 96; k++)
+      for (int c = 0; c < 16; c++) B[k * 16 + c] = (_Float16)1.0f;
+    for (int r = 0; r < 16; r++)
+      for (int k = 0; k < 96; k++) {
+        float a = 0.f;
+        const int fam = (t * 16 + r) & 3;
+        if (fam == 0) a = k == (r * 5) % 96 ? 4096.0f : 0.75f;                     // times b = 2048 / 1 below
+        else if (fam == 1) a = k >= 94 ? 0.f : ((k & 1) ? -1.f : 1.f) * (1024.0f + (float)(((k >> 1) * 7 + r) % 64) * ((k & 1) ? 0.5f : 0.53125f));
+        else if (fam == 2) a = 1.0009765625f;
+        else { const uint64_t u = next(); a = ((u & 1) ? -1.f : 1.f) * (1.0f + (float)((u >> 8) & 1023) / 1024.0f) * (float)(1u << ((u >> 20) % 12)); }
+        A[r * 96 + k] = (_Float16)a;
+      }
+    // column-side factors: column c scales family 0's big term to 2^23 and gives the others a second 11-bit factor
+    for (int k = 0; k < 96; k++)
+      for (int c = 0; c < 16; c++) {
+        const uint64_t u = next();
+        float b = 1.0f + (float)((u >> 5) % 1024) / 1024.0f;                          // [1, 2): full 11-bit significand
+        if ((c & 3) == 0) b = 1.0f;
+        if ((c & 3) == 1) b = 1.0009765625f;
+        B[k * 16 + c] = (_Float16)b;
+      }
+    for (int c = 0; c < 16; c++)  // family 0 rows meet their 2048 on one k only (any column): overwrite that k's factor
+      for (int r = 0; r < 16; r++)
+        if (((t * 16 + r) & 3) == 0) B[((r * 5) % 96) * 16 + c] = (_Float16)2048.0f;
+  }
+  _Float16 *dA = nullptr, *dB = nullptr;
+  float* dO = nullptr;
+  hipError_t e;
+  if ((e = hipMalloc(reinterpret_cast<void**>(&dA), hA.size() * 2)) != hipSuccess) return e;
+  if ((e = hipMalloc(reinterpret_cast<void**>(&dB), hB.size() * 2)) != hipSuccess) { (void)hipFree(dA); return e; }
+  if ((e = hipMalloc(reinterpret_cast<void**>(&dO), (size_t)kCases * 256 * 4)) != hipSuccess) { (void)hipFree(dA); (void)hipFree(dB); return e; }
+  std::vector<float> got((size_t)kCases * 256);
+  e = hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice);
+  for (int t = 0; t < kCases && e == hipSuccess; t++) {
+    hipLaunchKernelGGL(fp16_accumulation_probe_kernel, dim3(1), dim3(64), 0, stream, dA + (size_t)t * 16 * 96, dB + (size_t)t * 96 * 16, dO + (size_t)t * 256);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e == hipSuccess) e = hipMemcpy(got.data(), dO, got.size() * 4, hipMemcpyDeviceToHost);
+  (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dO);
+  if (e != hipSuccess) return e;
+  double worst = 0.0;
+  bool fine = true;
+  for (int t = 0; t < kCases; t++)
+    for (int r = 0; r < 16; r++)
+      for (int c = 0; c < 16; c++) {
+        double exact = 0.0, mag = 0.0;
+        for (int k = 0; k < 96; k++) {
+          const double p = (double)(float)hA[((size_t)t * 16 + r) * 96 + k] * (double)(float)hB[((size_t)t * 96 + k) * 16 + c];
+          exact += p;  // exact: every product has <= 22 significant bits within 2^-10 .. 2^24
+          mag += p < 0 ? -p : p;
+        }
+        const double err = std::fabs((double)got[(size_t)t * 256 + r * 16 + c] - exact);
+        const double ratio = err / (mag * 5.9604644775390625e-8);
+        if (!(ratio <= 87.0)) fine = false;  // (NaN fails)
+        if (ratio > worst || ratio != ratio) worst = ratio;
+      }
+  *ok = fine;
+  if (worst_ratio) *worst_ratio = worst;
   return hipSuccess;
 }
 

@@ -85,6 +85,8 @@ hipError_t launch_gmm_prefilter(const GmmPrefilterArgs& a, int ks32, hipStream_t
 int gmm_prefilter_frames_per_tile();
 // does the fp16 MFMA keep subnormal inputs on this device / in this build (an assumption of the prefilter's error bound)?
 hipError_t probe_fp16_denormals(hipStream_t stream, bool* preserved);
+// does the fp16 MFMA chain accumulate within the bound's model (|error| <= 87 * 2^-24 * sum |a_k b_k| on adversarial dot products)?
+hipError_t probe_fp16_accumulation(hipStream_t stream, bool* ok, double* worst_ratio);
 int gmm_refine_slots(uint32_t max_dens);
 hipError_t launch_gmm_refine(const GmmRefineArgs& a, hipStream_t stream);
 hipError_t launch_transpose_feats(const float* feats, uint64_t n_frames, uint32_t dim, uint64_t ldT, float* out, hipStream_t stream);

@@ -262,6 +262,9 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
     bool preserved = false;
     HIP_TRY(probe_fp16_denormals(m->s_gmm, &preserved));
     if (!preserved) return SR_OK;  // the bound of gmm_prefilter.hip does not hold with flushed subnormals: exact kernel
+    bool accumulates = false;
+    HIP_TRY(probe_fp16_accumulation(m->s_gmm, &accumulates, nullptr));
+    if (!accumulates) return SR_OK;  // ... nor with an accumulator outside its model
   }
   // A mixture of more than 32 densities is cut into Cs = 2 or 4 chunks of 32: the kernels see S*Cs pseudo-states
   // (ps = st*Cs + chunk), the prefilter takes the minimum across a state's chunks, the refinement folds them.
@@ -497,8 +500,8 @@ int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm
     if ((rc = prof_end(m, m->s_gmm, &ep_r))) return rc;
     if ((rc = prof_end(m, m->s_gmm, &ep))) return rc;
   } else if (gmm_kernel == SR_GMM_EXACT || gmm_kernel == SR_GMM_PREFILTER) {
-    // (a model the prefilter cannot take -- sum scoring, > 32 densities per mixture, dim > 47 -- is scored by the
-    // exact kernel: same bits, FP64 VALU speed)
+    // (a model the prefilter cannot take -- sum scoring, > 128 densities per mixture, dim > 46, or a device that fails
+    // the fp16 probes -- is scored by the exact kernel: same bits, FP64 VALU speed)
     GmmExactArgs a{};
     a.feats = d_feats; a.n_frames = n_frames; a.dim = m->dim; a.n_states = m->n_states;
     a.dens_off = m->dens_off.p; a.means = m->means.p; a.inv_vars = m->inv_vars.p; a.norm = m->norm.p; a.logw = m->logw.p;
@@ -1334,6 +1337,19 @@ int sr_accumulate_corpus(sr_model* m, sr_corpus* c, const uint16_t* states, int 
   HIP_TRY(hipMemcpy(mean_w, c->w_mean.p, sizeof(double) * m->n_mean, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(var_acc, c->acc_var.p, sizeof(double) * (size_t)m->n_var * D, hipMemcpyDeviceToHost));
   HIP_TRY(hipMemcpy(var_w, c->w_var.p, sizeof(double) * m->n_var, hipMemcpyDeviceToHost));
+  return SR_OK;
+  });
+}
+
+int sr_probe_fp16_accumulation(int device, int* within_model, double* worst_ratio) {
+  return guarded(__func__, [&]() -> int {
+  if (!within_model) return fail(SR_EINVAL, "within_model is null");
+  HIP_TRY(hipSetDevice(device));
+  bool ok = false;
+  double worst = 0.0;
+  HIP_TRY(probe_fp16_accumulation(nullptr, &ok, &worst));
+  *within_model = ok ? 1 : 0;
+  if (worst_ratio) *worst_ratio = worst;
   return SR_OK;
   });
 }

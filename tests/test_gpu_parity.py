@@ -566,3 +566,44 @@ def test_handles_give_their_device_memory_back(tmp_path):
         torch.cuda.synchronize()
         free.append(torch.cuda.mem_get_info()[0])
     assert free[-1] >= free[2] - (1 << 20), free  # (the first iterations warm up runtime pools)
+
+
+@pytest.mark.parametrize("S,M,D", [(24, 16, 39), (13, 64, 39), (9, 8, 25)])
+def test_prefilter_overflow_and_nonfinite_features(tmp_path, oracle_lib, S, M, D):
+    """Features the fp16 stage cannot represent: |x| = 256 and 300 (the square leaves fp16's range: inf), 1e4, 7e4 (x itself
+    does), +-inf and NaN.  Their frames' prefilter scores are inf/NaN, every density stays a candidate, and the FP64 stage
+    decides alone: SR_GMM_PREFILTER == SR_GMM_EXACT == MixtureModel::score bit for bit (NaN scores never win: 1e10)."""
+    rng = np.random.default_rng(S * 100 + M)
+    spec = synth.make_mixset(S, M, D, seed=S + M)
+    mp = str(tmp_path / "ovf.mix")
+    synth.write_mixset(mp, spec)
+    T = 300
+    feats = rng.standard_normal((T, D)).astype(np.float32)
+    specials = [255.0, 256.0, -256.0, 300.0, 1e4, -1e4, 65504.0, 7e4, 3e38, np.inf, -np.inf, np.nan]
+    for i, v in enumerate(specials):
+        feats[10 + i, (3 * i) % D] = v
+        feats[40 + i, :] = v            # the whole frame
+    feats[70, 0], feats[70, 1] = np.inf, -np.inf
+    feats[71, 0], feats[71, 1] = np.nan, 300.0
+    lex = synth.make_lexicon(max(1, (S - 1) // 3), 3, 1, extra_states_last=(S - 1) % 3)
+    o = oracle_lib.Oracle(mp, D, lex)
+    want = o.score_matrix(feats)
+    o.close()
+    with capi.Model.from_mixset(mp, D) as m:
+        got = m.score_frames(feats, capi.GMM_PREFILTER)
+        exact = m.score_frames(feats, capi.GMM_EXACT)
+    assert np.array_equal(exact.view(np.uint64), want.view(np.uint64))
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    assert np.all(want[40 + specials.index(np.nan)] == 1e10)  # an all-NaN frame: every state keeps min_score's seed
+
+
+def test_fp16_accumulation_stays_inside_the_bounds_model():
+    """The other hardware assumption of the prefilter's error bound: fp32 accumulation inside the MFMA chain errs by at most
+    2^-24 of the running magnitude per addition (87 additions at K = 96).  Adversarial dot products with known exact sums;
+    the library runs the same probe at model creation and falls back to the exact kernel if it fails."""
+    import ctypes as C
+
+    ok, worst = C.c_int(0), C.c_double(0.0)
+    assert capi.lib().sr_probe_fp16_accumulation(0, C.byref(ok), C.byref(worst)) == 0
+    print(f"worst |error| / (2^-24 sum|ab|) = {worst.value:.3f} (model: 87)")
+    assert ok.value == 1 and worst.value <= 87.0
