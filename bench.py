@@ -3,15 +3,18 @@
 
 Workload (BASELINE.json configs[2]): 4000 tied states (silence + 1333 three-state words),
 32-mixture diagonal GMM (128 000 densities), 39-dim float32 features, a batch of 1000 synthetic
-utterances (lengths U{200..400}, i.i.d. N(0,1) frames) PER GPU, beam (am-threshold) 200, word penalty 10,
-TDP 3/0/30.  A "step" is one full pass over the resident batch: dense GMM scoring of every frame
-(FP64 MFMA kernel) + beam Viterbi decode of every utterance + recognised words back on the host.
-Features are resident in HBM before the timed region (sr_corpus_upload); results leave the device
-inside it.
+utterances (lengths U{200..400}, i.i.d. N(0,1) frames) per GPU, beam (am-threshold) 200, word penalty 10,
+TDP 3/0/30.  A "step" is one full pass over the resident batch: exact GMM scoring of every (frame, state)
+(default: fp16 MFMA prefilter + FP64 refinement, bit-identical to MixtureModel::score) + beam Viterbi decode
+of every utterance + recognised words back on the host.  Features are resident in HBM before the timed region
+(sr_corpus_upload); results leave the device inside it.
 
-Multi-GPU: one process per GPU (torchrun), each rank decodes its own shard of utterances with a full
-model replica; there is no data-path collective (utterances are independent, Recognizer.cpp:46-47).
-torch.distributed is used only for the barrier and the max-over-ranks of the step time.
+Multi-GPU (`--gpus N`): ONE batch of N x 1000 utterances (or `--total-utts T`: configs[3] = `--gpus 8 --total-utts 10000`)
+is generated from a shared seed and dealt to the ranks by frames (greedy longest-processing-time, the same deal
+sr_shard_utterances makes); one process per GPU (torchrun), each rank holds a full model replica and decodes its
+shard; there is no data-path collective (utterances are independent, Recognizer.cpp:46-47).  torch.distributed
+is used only for the barrier and the max-over-ranks of the step time.  Started without torchrun, `--gpus N`
+starts it as a child process (before anything touches the GPU) and relays its JSON line.
 
 Prints ONE JSON line on rank 0 (contract in the task description) with `roofline` (GMM kernel, timed with
 HIP events on its launch stream by libsrgpu's sr_profile_*) and, at N=1, `cpu_baseline` (the CPU oracle's
@@ -40,8 +43,14 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--utts", type=int, default=1000, help="utterances per GPU")
+    ap.add_argument("--utts", type=int, default=1000, help="utterances per GPU (the batch holds utts x gpus)")
+    ap.add_argument("--total-utts", type=int, default=0, help="size of the whole batch instead (strong scaling: fixed as N grows)")
     ap.add_argument("--words", type=int, default=1333, help="three-state words (states = 1 + 3*words)")
+    ap.add_argument("--extra-states-last", type=int, default=0, help="extra states of the last word (configs[4]: --words 2666 "
+                    "--extra-states-last 1 --mix 64 gives 8000 states)")
+    ap.add_argument("--config", choices=["cfg3", "cfg4", "cfg5"], default=None,
+                    help="presets: cfg3 = BASELINE configs[2] (default), cfg4 = configs[3] (--total-utts 10000), "
+                         "cfg5 = configs[4] (8000 states x 64, bigram search)")
     ap.add_argument("--mix", type=int, default=32)
     ap.add_argument("--beam", type=float, default=200.0)
     ap.add_argument("--kernel", choices=["mfma", "exact", "prefilter"], default="prefilter",
@@ -54,11 +63,36 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals "
                     "where several ranks share one GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the cpu_baseline leg")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.config == "cfg4":
+        args.total_utts = 10000
+    if args.config == "cfg5":
+        args.words, args.extra_states_last, args.mix, args.decoder = 2666, 1, 64, "bigram"
+    return args
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` without torchrun: start it as a CHILD process (never exec: nothing here has touched the GPU
+    yet, and it must stay that way) and relay its output and exit code."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus and os.environ.get("SR_BENCH_FORCE_DIST") != "1":
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}\n")
+        sys.exit(2)
     # Only the JSON line may reach stdout: libraries write banners there (RCCL prints its version block when the first
     # communicator comes up), so fd 1 points at stderr for the whole run and the result goes to the saved descriptor.
     sys.stdout.flush()
@@ -80,17 +114,23 @@ def main():
         else:
             dist.init_process_group(backend=args.dist_backend)
 
-    from speechrecognition_amd import capi, synth
+    from speechrecognition_amd import capi, sharding, synth
 
     D = 39
-    lex = synth.make_lexicon(args.words, 3, 1)
+    lex = synth.make_lexicon(args.words, 3, 1, extra_states_last=args.extra_states_last)
     S = lex.n_states
     tdp, wp = (3.0, 0.0, 30.0), 10.0
     tmp = tempfile.mkdtemp(prefix=f"srbench{rank}_")
     mixset_path = os.path.join(tmp, "model.mix")
     spec = synth.make_mixset(S, args.mix, D, seed=23)       # same model on every rank (replicated, read-only)
     synth.write_mixset(mixset_path, spec)
-    feats, frame_off = synth.make_batch(args.utts, 200, 400, D, seed=7 + 1000 * rank)  # this rank's shard
+    # ONE batch for the whole job, the same on every rank (shared seed), dealt to the ranks by frames (greedy LPT)
+    total_utts = args.total_utts or args.utts * world
+    all_feats, all_off = synth.make_batch(total_utts, 200, 400, D, seed=7)
+    shards = sharding.shard_utterances(all_off, world)
+    shard_frames = [int(np.diff(all_off.astype(np.int64))[sh].sum()) for sh in shards]
+    feats, frame_off = (all_feats, all_off) if world == 1 else sharding.take_shard(all_feats, all_off, shards[rank])
+    del all_feats
     n_frames = int(frame_off[-1])
     word_off, automaton, sil_state = lex.flatten()
     kernel = {"mfma": capi.GMM_MFMA, "exact": capi.GMM_EXACT, "prefilter": capi.GMM_PREFILTER}[args.kernel]
@@ -135,8 +175,6 @@ def main():
     prof = model.profile_read()
     model.profile(False)
 
-    from speechrecognition_amd import sharding
-
     elapsed, total_frames = sharding.reduce_timing(elapsed, n_frames, dist if distributed else None,
                                                    torch.device("cuda", device) if args.dist_backend == "nccl" else None)
 
@@ -155,16 +193,19 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.total_utts else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": f"{S} states x {args.mix}-mix diag GMM ({S * args.mix} densities), 39-d float32 frames, "
-                            f"{args.utts} utterances/GPU U{{200..400}} frames, beam {args.beam:g}, dense scoring + beam Viterbi",
-                "states": S, "mixtures": args.mix, "feat_dim": D, "utterances_per_gpu": args.utts,
-                "frames_per_gpu_rank0": n_frames, "words": lex.n_words, "trellis_positions": int(word_off[-1]),
-                "gmm_kernel": args.kernel, "parallelism": f"utterance-shard x{world}, no collective",
+                            f"one batch of {total_utts} utterances U{{200..400}} frames ({int(all_off[-1])} frames), beam {args.beam:g}, "
+                            f"exact scoring of every (frame, state) + beam Viterbi",
+                "states": S, "mixtures": args.mix, "feat_dim": D, "utterances_total": total_utts,
+                "utterances_rank0": len(frame_off) - 1, "frames_rank0": n_frames, "words": lex.n_words,
+                "trellis_positions": int(word_off[-1]), "gmm_kernel": args.kernel,
+                "parallelism": f"utterance-shard x{world} (greedy LPT by frames), no collective",
+                "shard_imbalance": max(shard_frames) / (sum(shard_frames) / world),  # heaviest shard / mean: what strong scaling can lose
             },
             "roofline": gmm_roofline(args, prof, n_frames, D, S),
             "search": {

@@ -25,6 +25,7 @@
 #include <cstdint>
 #include <fstream>
 #include <limits>
+#include <memory>
 #include <stdexcept>
 #include <time.h>
 #include <string>
@@ -120,7 +121,8 @@ class MixtureModel : public FeatureScorer {
   // "load-mixtures-from" = path (Mixtures.cpp:156-174)
   MixtureModel(std::string const& load_mixtures_from, size_t dimension, VarianceModel var_model, bool max_approx,
                int device = 0, int gmm_kernel = SR_GMM_PREFILTER)
-      : dimension(dimension), var_model(var_model), gmm_kernel(gmm_kernel) {
+      : dimension(dimension), var_model(var_model), gmm_kernel(gmm_kernel), path_(load_mixtures_from), max_approx_(max_approx),
+        device_(device) {
     check(sr_model_load_mixset(load_mixtures_from.c_str(), (uint32_t)dimension, (int)var_model, max_approx ? 1 : 0, device, &h_));
     uint32_t d, s;
     uint64_t c;
@@ -139,6 +141,12 @@ class MixtureModel : public FeatureScorer {
   size_t num_mixtures() const { return num_mixtures_; }
   size_t num_densities() const { return num_densities_; }
   sr_model* handle() const { return h_; }
+  int device() const { return device_; }
+  // another replica of the same model file on `device` (utterance batches shard across devices, every device holds the
+  // whole model: Recognizer::recognize(corpus, devices))
+  std::unique_ptr<MixtureModel> replicate(int device) const {
+    return std::unique_ptr<MixtureModel>(new MixtureModel(path_, dimension, var_model, max_approx_, device, gmm_kernel));
+  }
 
   // FeatureScorer: one dense [T x S] table per sequence
   void prepare_sequence(const float* begin, size_t n_frames) override {
@@ -151,6 +159,9 @@ class MixtureModel : public FeatureScorer {
   sr_model* h_ = nullptr;
   size_t num_mixtures_ = 0, num_densities_ = 0;
   std::vector<double> table_;
+  std::string path_;
+  bool max_approx_ = true;
+  int device_ = 0;
 };
 
 // ---- Corpus.hpp:55-84: contiguous features + offsets + reference word sequences ---------------------------
@@ -207,6 +218,7 @@ struct RecognitionStats {  // what Recognizer::recognize prints (Recognizer.cpp:
   size_t ref_words = 0, sentence_errors = 0, corpus_size = 0;
   double wer = 0, ser = 0, seconds = 0, rtf = 0;
   std::vector<std::vector<WordIdx>> hypotheses;
+  std::vector<uint64_t> frames_per_device;  // recognize(corpus, devices): how the LPT deal loaded the devices
 };
 
 class Recognizer {
@@ -217,18 +229,20 @@ class Recognizer {
              double word_penalty = 10.0, size_t max_recognition_runs = 1000)
       : am_threshold_(am_threshold), word_penalty_(word_penalty), max_recognition_runs_(max_recognition_runs),
         lexicon_(lexicon), scorer_(scorer) {
-    std::vector<uint32_t> word_off(1, 0);
-    std::vector<uint16_t> automaton;
+    word_off_.assign(1, 0);
     for (WordIdx w = 0; w < lexicon.num_words(); w++) {
       auto const& a = lexicon.get_automaton_for_word(w);
-      automaton.insert(automaton.end(), a.states.begin(), a.states.end());
-      word_off.push_back((uint32_t)automaton.size());
+      automaton_.insert(automaton_.end(), a.states.begin(), a.states.end());
+      word_off_.push_back((uint32_t)automaton_.size());
     }
-    const double tdp[3] = {tdp_model.tdp_loop, tdp_model.tdp_forward, tdp_model.tdp_skip};
-    check(sr_lexicon_create(scorer.handle(), (uint32_t)lexicon.num_words(), word_off.data(), automaton.data(),
-                            (uint32_t)lexicon.silence_idx(), tdp, tdp_model.silence_state, &net_));
+    tdp_[0] = tdp_model.tdp_loop; tdp_[1] = tdp_model.tdp_forward; tdp_[2] = tdp_model.tdp_skip;
+    silence_state_ = tdp_model.silence_state;
+    net_ = make_net(scorer);
   }
-  ~Recognizer() { sr_lexicon_destroy(net_); }
+  ~Recognizer() {
+    for (auto& r : replicas_) sr_lexicon_destroy(r.net);
+    sr_lexicon_destroy(net_);
+  }
   Recognizer(Recognizer const&) = delete;
 
   // Recognizer::recognizeSequence_pruned (Recognizer.cpp:103-232)
@@ -241,8 +255,13 @@ class Recognizer {
     output.assign(words.begin(), words.begin() + woff[1]);
   }
 
-  // Recognizer::recognize (Recognizer.cpp:38-92): the whole corpus in one device pass
-  RecognitionStats recognize(Corpus const& corpus) {
+  // Recognizer::recognize (Recognizer.cpp:38-92): the whole corpus in one device pass.
+  // With `devices`: the reference's `#pragma omp parallel for` over segments (:46-47) at device granularity -- the
+  // segments are dealt to the devices by frames (greedy LPT), every device gets a replica of the model and of the search
+  // network (created on first use, kept) and one host thread that feeds and recognises its shard; hypotheses come back in
+  // corpus order.  A device may be listed more than once (two replicas on it).  No collective.
+  RecognitionStats recognize(Corpus const& corpus) { return recognize(corpus, std::vector<int>()); }
+  RecognitionStats recognize(Corpus const& corpus, std::vector<int> const& devices) {
     RecognitionStats st;
     const size_t n = std::min(corpus.get_corpus_size(), max_recognition_runs_);
     st.corpus_size = n;
@@ -250,9 +269,37 @@ class Recognizer {
     std::vector<uint32_t> words(std::max<uint64_t>(total, 1));
     std::vector<uint64_t> woff(n + 1);
     const sr_search_params p = {am_threshold_, word_penalty_, scorer_.gmm_kernel, 0};
-    const double t0 = now();
-    check(sr_recognize_batch(scorer_.handle(), net_, &p, corpus.features(), corpus.frame_offsets(), (uint32_t)n,
-                             words.data(), woff.data()));
+    double t0;
+    if (devices.size() <= 1 && (devices.empty() || devices[0] == scorer_.device())) {
+      t0 = now();
+      check(sr_recognize_batch(scorer_.handle(), net_, &p, corpus.features(), corpus.frame_offsets(), (uint32_t)n,
+                               words.data(), woff.data()));
+    } else {
+      std::vector<sr_model*> models;
+      std::vector<sr_lexicon*> nets;
+      std::vector<size_t> used(replicas_.size(), 0);
+      bool own_used = false;
+      for (int dev : devices) {  // the recogniser's own model serves its device once, replicas the rest
+        if (dev == scorer_.device() && !own_used) { own_used = true; models.push_back(scorer_.handle()); nets.push_back(net_); continue; }
+        size_t r = 0;
+        for (; r < replicas_.size(); r++)
+          if (replicas_[r].model->device() == dev && !used[r]) break;
+        if (r == replicas_.size()) {
+          Replica rep;
+          rep.model = scorer_.replicate(dev);
+          rep.net = make_net(*rep.model);
+          replicas_.push_back(std::move(rep));
+          used.push_back(0);
+        }
+        used[r] = 1;
+        models.push_back(replicas_[r].model->handle());
+        nets.push_back(replicas_[r].net);
+      }
+      st.frames_per_device.assign(devices.size(), 0);
+      t0 = now();
+      check(sr_recognize_batch_multi(models.data(), nets.data(), (uint32_t)models.size(), &p, corpus.features(),
+                                     corpus.frame_offsets(), (uint32_t)n, words.data(), woff.data(), st.frames_per_device.data()));
+    }
     st.seconds = now() - t0;
     for (size_t s = 0; s < n; s++) {
       std::vector<WordIdx> hyp(words.begin() + woff[s], words.begin() + woff[s + 1]);
@@ -304,11 +351,26 @@ class Recognizer {
     clock_gettime(CLOCK_MONOTONIC, &ts);  // Timer.hpp:11-40
     return ts.tv_sec + 1e-9 * ts.tv_nsec;
   }
+  sr_lexicon* make_net(MixtureModel& scorer) const {
+    sr_lexicon* net = nullptr;
+    check(sr_lexicon_create(scorer.handle(), (uint32_t)lexicon_.num_words(), word_off_.data(), automaton_.data(),
+                            (uint32_t)lexicon_.silence_idx(), tdp_, silence_state_, &net));
+    return net;
+  }
+  struct Replica {
+    std::unique_ptr<MixtureModel> model;
+    sr_lexicon* net = nullptr;
+  };
   const double am_threshold_, word_penalty_;
   const size_t max_recognition_runs_;
   Lexicon const& lexicon_;
   MixtureModel& scorer_;
+  std::vector<uint32_t> word_off_;
+  std::vector<uint16_t> automaton_;
+  double tdp_[3] = {0, 0, 0};
+  StateIdx silence_state_ = 0;
   sr_lexicon* net_ = nullptr;
+  std::vector<Replica> replicas_;
 };
 
 // ---- Alignment.hpp:19-63 -------------------------------------------------------------------------------------

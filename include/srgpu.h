@@ -89,6 +89,13 @@ SR_API int sr_model_info(const sr_model* m, uint32_t* dim, uint32_t* n_states, u
  * Copies n_utts concatenated utterances to the device. frame_off[n_utts+1], frame_off[0] == 0.
  * The host buffer is borrowed for the duration of the call only. */
 SR_API int sr_corpus_upload(sr_model* m, const float* feats, const uint64_t* frame_off, uint32_t n_utts, sr_corpus** out);
+/* The frame-batch feeder proper: like sr_corpus_upload, but it returns as soon as the handle exists.  A feeder thread copies
+ * the host buffer in 8 MiB pieces through two pinned staging buffers on the corpus' own copy stream; the compute entry
+ * points below wait -- on the device, per score chunk -- only for the pieces a chunk needs, so the transfer of later
+ * utterances overlaps the scoring of earlier ones.  The host buffer is borrowed until sr_corpus_wait() has returned (or
+ * the corpus has been destroyed); sr_corpus_wait returns the feeder's status.  sr_recognize_batch feeds this way. */
+SR_API int sr_corpus_upload_async(sr_model* m, const float* feats, const uint64_t* frame_off, uint32_t n_utts, sr_corpus** out);
+SR_API int sr_corpus_wait(sr_corpus* c);
 SR_API int sr_corpus_destroy(sr_corpus* c);
 
 /* ---- scoring: FeatureScorer::prepare_sequence + score (FeatureScorer.hpp:14-15) -------------------
@@ -134,6 +141,19 @@ SR_API int sr_recognize_corpus(sr_model* m, sr_corpus* c, sr_lexicon* l, const s
 /* one-shot convenience: upload + recognise + free */
 SR_API int sr_recognize_batch(sr_model* m, sr_lexicon* l, const sr_search_params* p, const float* feats,
                        const uint64_t* frame_off, uint32_t n_utts, uint32_t* out_words, uint64_t* out_word_off);
+
+/* ---- several devices: the `#pragma omp parallel for` over segments of Recognizer::recognize (Recognizer.cpp:46-47) -------
+ * Utterances are independent, so a batch shards across devices with no collective: sr_shard_utterances deals them by
+ * greedy longest-processing-time on frame counts (decreasing length, each to the lightest shard so far; deterministic);
+ * shard_of_utt[n_utts] receives the shard of every utterance, shard_frames[n_shards] (may be NULL) the frames per shard.
+ * sr_recognize_batch_multi runs one host thread per (model, lexicon) replica -- models[d] on its own device, or several
+ * replicas on one device -- which feeds (sr_corpus_upload_async, straight from the caller's buffer) and recognises its
+ * shard; the word sequences come back in corpus order, exactly what sr_recognize_batch returns on one device. */
+SR_API int sr_shard_utterances(const uint64_t* frame_off, uint32_t n_utts, uint32_t n_shards, uint32_t* shard_of_utt,
+                               uint64_t* shard_frames);
+SR_API int sr_recognize_batch_multi(sr_model* const* models, sr_lexicon* const* lexica, uint32_t n_devices,
+                                    const sr_search_params* p, const float* feats, const uint64_t* frame_off, uint32_t n_utts,
+                                    uint32_t* out_words, uint64_t* out_word_off, uint64_t* shard_frames);
 
 /* ---- forced aligner: Aligner::align_sequence_full (Alignment.cpp:50-144) --------------------------
  * Utterance u is aligned against automata[aut_off[u] .. aut_off[u+1]) (N_u state ids; training

@@ -22,7 +22,7 @@ SEARCH_GENERAL_KERNEL = 1
 # every symbol include/srgpu.h declares
 SYMBOLS = [
     "sr_last_error", "sr_device_count", "sr_model_create", "sr_model_load_mixset", "sr_model_destroy", "sr_model_info",
-    "sr_corpus_upload", "sr_corpus_destroy", "sr_score_corpus", "sr_score_frames", "sr_lexicon_create",
+    "sr_corpus_upload", "sr_corpus_upload_async", "sr_corpus_wait", "sr_corpus_destroy", "sr_shard_utterances", "sr_recognize_batch_multi", "sr_score_corpus", "sr_score_frames", "sr_lexicon_create",
     "sr_lexicon_destroy", "sr_recognize_corpus", "sr_recognize_batch", "sr_align_corpus", "sr_align_corpus_pruned", "sr_path_scores_corpus", "sr_model_create_from_statistics", "sr_mixset_write", "sr_model_set_tying", "sr_model_tying_info", "sr_accumulate_corpus",
     "sr_bigram_create", "sr_bigram_destroy", "sr_recognize_bigram_corpus",
     "sr_probe_fp16_denormals", "sr_probe_fp16_accumulation",
@@ -70,6 +70,10 @@ def lib():
         L.sr_model_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u64)]
         L.sr_corpus_upload.argtypes = [vp, vp, vp, u32, C.POINTER(vp)]
         L.sr_corpus_destroy.argtypes = [vp]
+        L.sr_corpus_upload_async.argtypes = [vp, vp, vp, u32, C.POINTER(vp)]
+        L.sr_corpus_wait.argtypes = [vp]
+        L.sr_shard_utterances.argtypes = [vp, u32, u32, vp, vp]
+        L.sr_recognize_batch_multi.argtypes = [vp, vp, u32, C.POINTER(SearchParams), vp, vp, u32, vp, vp, vp]
         L.sr_score_corpus.argtypes = [vp, vp, i32, vp]
         L.sr_score_frames.argtypes = [vp, vp, u64, i32, vp]
         L.sr_lexicon_create.argtypes = [vp, u32, vp, vp, u32, C.POINTER(dbl * 3), C.c_uint16, C.POINTER(vp)]
@@ -167,8 +171,19 @@ class Model:
         _check(lib().sr_score_frames(self.h, _ptr(feats), feats.shape[0], kernel, _ptr(out)))
         return out
 
-    def upload(self, feats, frame_off):
-        return Corpus(self, feats, frame_off)
+    def upload(self, feats, frame_off, asynchronous=False):
+        return Corpus(self, feats, frame_off, asynchronous)
+
+    def recognize_batch(self, lexicon, feats, frame_off, am_threshold, word_penalty, kernel=GMM_PREFILTER):
+        """sr_recognize_batch: host buffers in, words out (fed asynchronously while the first chunks are scored)."""
+        feats = np.ascontiguousarray(feats, dtype=np.float32)
+        frame_off = np.ascontiguousarray(frame_off, dtype=np.uint64)
+        n = len(frame_off) - 1
+        words = np.zeros(max(int(frame_off[-1]), 1), dtype=np.uint32)
+        woff = np.zeros(n + 1, dtype=np.uint64)
+        sp = SearchParams(am_threshold, word_penalty, kernel, 0)
+        _check(lib().sr_recognize_batch(self.h, lexicon.h, C.byref(sp), _ptr(feats), _ptr(frame_off), n, _ptr(words), _ptr(woff)))
+        return words[: int(woff[-1])].copy(), woff
 
     def lexicon(self, word_off, automaton, silence_idx, tdp, silence_state):
         return Lexicon(self, word_off, automaton, silence_idx, tdp, silence_state)
@@ -214,14 +229,22 @@ class Bigram:
 class Corpus:
     """sr_corpus handle: device-resident utterance batch (Corpus layout, sietill/Corpus.cpp:89-111)."""
 
-    def __init__(self, model, feats, frame_off):
+    def __init__(self, model, feats, frame_off, asynchronous=False):
         self.model = model
         feats = np.ascontiguousarray(feats, dtype=np.float32)
         self.frame_off = np.ascontiguousarray(frame_off, dtype=np.uint64)
         self.n_utts = len(self.frame_off) - 1
         self.n_frames = int(self.frame_off[-1])
         self.h = C.c_void_p()
-        _check(lib().sr_corpus_upload(model.h, _ptr(feats), _ptr(self.frame_off), self.n_utts, C.byref(self.h)))
+        if asynchronous:  # the feeder borrows `feats` until wait() / close()
+            self._borrowed = feats
+            _check(lib().sr_corpus_upload_async(model.h, _ptr(feats), _ptr(self.frame_off), self.n_utts, C.byref(self.h)))
+        else:
+            _check(lib().sr_corpus_upload(model.h, _ptr(feats), _ptr(self.frame_off), self.n_utts, C.byref(self.h)))
+
+    def wait(self):
+        _check(lib().sr_corpus_wait(self.h))
+        self._borrowed = None
 
     def close(self):
         if self.h:
@@ -321,3 +344,28 @@ def mixset_write(path, dim, dens_off, dens_mean, dens_var, acc):
     ma, mw, va, vw = (np.ascontiguousarray(x, dtype=np.float64) for x in acc)
     _check(lib().sr_mixset_write(str(path).encode(), dim, len(dens_off) - 1, _ptr(dens_off), len(mw), len(vw), _ptr(dens_mean),
                                  _ptr(dens_var), _ptr(ma), _ptr(mw), _ptr(va), _ptr(vw)))
+
+
+def shard_utterances(frame_off, n_shards):
+    """sr_shard_utterances: greedy LPT deal by frames -> (shard_of_utt u32[n_utts], shard_frames u64[n_shards])."""
+    frame_off = np.ascontiguousarray(frame_off, dtype=np.uint64)
+    n = len(frame_off) - 1
+    shard = np.zeros(max(n, 1), dtype=np.uint32)
+    load = np.zeros(n_shards, dtype=np.uint64)
+    _check(lib().sr_shard_utterances(_ptr(frame_off), n, n_shards, _ptr(shard), _ptr(load)))
+    return shard[:n], load
+
+
+def recognize_batch_multi(models, lexica, feats, frame_off, am_threshold, word_penalty, kernel=GMM_PREFILTER):
+    """sr_recognize_batch_multi over (model, lexicon) replicas, one host thread each -> (words, word_off, shard_frames)."""
+    feats = np.ascontiguousarray(feats, dtype=np.float32)
+    frame_off = np.ascontiguousarray(frame_off, dtype=np.uint64)
+    n, nd = len(frame_off) - 1, len(models)
+    mh = (C.c_void_p * nd)(*[m.h for m in models])
+    lh = (C.c_void_p * nd)(*[l.h for l in lexica])
+    words = np.zeros(max(int(frame_off[-1]), 1), dtype=np.uint32)
+    woff = np.zeros(n + 1, dtype=np.uint64)
+    load = np.zeros(nd, dtype=np.uint64)
+    sp = SearchParams(am_threshold, word_penalty, kernel, 0)
+    _check(lib().sr_recognize_batch_multi(mh, lh, nd, C.byref(sp), _ptr(feats), _ptr(frame_off), n, _ptr(words), _ptr(woff), _ptr(load)))
+    return words[: int(woff[-1])].copy(), woff, load

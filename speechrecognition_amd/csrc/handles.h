@@ -1,0 +1,159 @@
+// handles.h -- the opaque handle types of the C ABI (include/srgpu.h) and the small helpers the translation units that
+// implement it share (srgpu_api.cpp: compute entry points; feeder.cpp: frame-batch feeder and multi-device driver).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/srgpu.h"
+#include "host_util.h"
+#include "kernels.h"
+
+namespace srhost {
+// stores a printf-style message for sr_last_error() (thread-local) and returns `code`
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+}  // namespace srhost
+
+#define HIP_TRY(expr)                                                                             \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) return srhost::fail(SR_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  hipError_t ensure(size_t count) {
+    if (count <= n && p) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; n = 0; }
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
+    if (e == hipSuccess) n = count;
+    return e;
+  }
+  hipError_t upload(const T* src, size_t count) {
+    hipError_t e = ensure(count);
+    if (e != hipSuccess || count == 0) return e;
+    return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  // handles own their buffers: whatever a destroy function does not release by name goes with the object
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+};
+
+struct EventPair { hipEvent_t a, b; int kind; };  // kind 0 = gmm, 1 = search, 2 = prefilter pass, 3 = refinement (inside 0)
+
+
+struct sr_feeder;  // feeder.cpp: the asynchronous upload of a corpus
+
+
+struct sr_model {
+  int device = 0;
+  uint32_t dim = 0, n_states = 0, ld = 0;
+  uint64_t n_dens = 0;
+  bool max_approx = true;
+  // exact-kernel tables (finalised, per density)
+  DevBuf<uint32_t> dens_off;
+  DevBuf<double> means, inv_vars, norm, logw;
+  // EM tying (accumulator rows)
+  DevBuf<uint32_t> dens_mean, dens_var;
+  std::vector<uint32_t> h_dens_off;
+  // host copies of the finalised tables: the kernel-specific packings are built on first use of that kernel
+  std::vector<double> h_means, h_inv_vars, h_norm, h_logw;
+  bool mfma_packed = false, pf_packed = false;
+  uint32_t n_mean = 0, n_var = 0;
+  // MFMA packing
+  int ksteps = 0;
+  uint32_t n_blocks = 0, n_groups = 0;
+  DevBuf<double> apack;
+  DevBuf<uint32_t> blk_meta, grp_state;
+  std::vector<uint32_t> group_first_block;  // host: [n_groups+1]
+  DevBuf<uint32_t> split_begin;
+  uint32_t split_ny = 0;
+  // fp16 prefilter + FP64 refinement (gmm_prefilter.hip); pf_ks32 == 0: model not eligible
+  int pf_ks32 = 0;
+  uint32_t pf_groups = 0, pf_ny = 0, max_dens = 0, pf_slots = 0, pf_chunks = 1, pf_pstates = 0;
+  DevBuf<unsigned char> pf_apack;
+  DevBuf<float> pf_anorm, featsT;
+  DevBuf<uint32_t> pf_split, pf_mask, pf_ndens, pf_ring;
+  DevBuf<double> pf_rows;
+  DevBuf<unsigned long long> pf_counter;
+  // streams / workspace
+  hipStream_t s_gmm = nullptr, s_search = nullptr;
+  DevBuf<double> scores[2];
+  hipEvent_t ev_scored[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
+  size_t chunk_frames = 0;
+  bool overlap = true;  // search of chunk i on its own stream while chunk i+1 is scored (SRGPU_OVERLAP=0: one stream)
+  // profiling
+  bool profiling = false;
+  std::vector<EventPair> events;
+  sr_profile prof{};
+};
+
+struct sr_corpus {
+  sr_model* model = nullptr;
+  sr_feeder* feeder = nullptr;      // sr_corpus_upload_async: pieces still on their way (feeder.cpp)
+  uint32_t n_utts = 0;
+  uint64_t n_frames = 0;
+  std::vector<uint64_t> frame_off;  // host copy
+  DevBuf<float> feats;
+  DevBuf<uint64_t> d_frame_off;
+  // search outputs (device)
+  DevBuf<double> tb_score;
+  DevBuf<uint16_t> tb_word, tb_bkp;
+  DevBuf<uint32_t> out_words, out_count, out_flags;
+  // aligner workspace
+  DevBuf<uint16_t> automata, out_states;
+  DevBuf<uint64_t> aut_off, bp_off, al_blk_frame0;
+  DevBuf<uint32_t> al_list_off, al_states, al_blk_frames, al_blk_list;
+  DevBuf<uint8_t> backptr;
+  DevBuf<double> out_cost, path_scores;
+  // EM accumulation workspace
+  DevBuf<uint64_t> pair_off;
+  DevBuf<uint32_t> pair_frame, key_mean, key_var, iota, keys_sorted, pairs_sorted, row_begin;
+  DevBuf<double> pair_w, acc_mean, acc_var, w_mean, w_var;
+  DevBuf<unsigned char> sort_temp;
+};
+
+struct sr_lexicon {
+  sr_model* model = nullptr;
+  uint32_t n_words = 0, n_slots = 0, silence_idx = 0, silence_state = 0;
+  double tdp[3] = {0, 0, 0};
+  DevBuf<uint32_t> slot_info, slot_word, word_end_slot;
+  // type-sorted copy for the fast kernel
+  DevBuf<uint32_t> f_state, f_pred, f_orig, f_type, f_word;
+  uint32_t f_n = 0, f_init = 0, f_init_end = 0;
+};
+
+struct sr_bigram {
+  sr_model* model = nullptr;
+  uint32_t n_words = 0, silence = 0, n_positions = 0;
+  float tdp[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  DevBuf<uint32_t> slot_off, slot_mix;
+  DevBuf<uint16_t> mixtures;
+  DevBuf<float> lmT, lm_rowmin, lm_rowmax;
+  // workspace
+  DevBuf<uint32_t> we_slot, we_bp, out_word, out_time, out_count, out_flags;
+  DevBuf<float> we_score, out_score;
+  DevBuf<uint4> book;
+  DevBuf<uint64_t> book_off;
+};
+
+namespace srhost {
+// (feeder.cpp) make frames [f0, f1) of the corpus visible to work queued on `stream` afterwards: returns at once for a
+// synchronously uploaded corpus; for sr_corpus_upload_async it waits (host) until the feeder has issued the pieces that
+// cover the range and makes the stream wait for their copy events.  Returns the feeder's error, if any.
+int corpus_ready(sr_corpus* c, uint64_t f0, uint64_t f1, hipStream_t stream);
+bool corpus_upload_in_flight(const sr_corpus* c);
+void feeder_join(sr_corpus* c);  // blocks until the feeder thread (if any) has finished, frees its staging buffers
+}  // namespace srhost

@@ -25,10 +25,14 @@
 using namespace srgpu;
 using srhost::guarded;
 
+#include "handles.h"
+
+using srhost::fail;
+
 namespace {
-
 thread_local char g_err[512] = "";
-
+}  // namespace
+namespace srhost {
 int fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -36,138 +40,8 @@ int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
-
-}  // namespace
-namespace srhost {
 int set_error(int code, const char* msg) { return fail(code, "%s", msg); }
 }  // namespace srhost
-namespace {
-
-#define HIP_TRY(expr)                                                                             \
-  do {                                                                                            \
-    hipError_t e_ = (expr);                                                                       \
-    if (e_ != hipSuccess) return fail(SR_EHIP, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-  } while (0)
-
-template <typename T>
-struct DevBuf {
-  T* p = nullptr;
-  size_t n = 0;
-  hipError_t ensure(size_t count) {
-    if (count <= n && p) return hipSuccess;
-    if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; n = 0; }
-    if (count == 0) count = 1;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T));
-    if (e == hipSuccess) n = count;
-    return e;
-  }
-  hipError_t upload(const T* src, size_t count) {
-    hipError_t e = ensure(count);
-    if (e != hipSuccess || count == 0) return e;
-    return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
-  }
-  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
-  // handles own their buffers: whatever a destroy function does not release by name goes with the object
-  DevBuf() = default;
-  DevBuf(const DevBuf&) = delete;
-  DevBuf& operator=(const DevBuf&) = delete;
-  ~DevBuf() { release(); }
-};
-
-struct EventPair { hipEvent_t a, b; int kind; };  // kind 0 = gmm, 1 = search, 2 = prefilter pass, 3 = refinement (inside 0)
-
-}  // namespace
-
-struct sr_model {
-  int device = 0;
-  uint32_t dim = 0, n_states = 0, ld = 0;
-  uint64_t n_dens = 0;
-  bool max_approx = true;
-  // exact-kernel tables (finalised, per density)
-  DevBuf<uint32_t> dens_off;
-  DevBuf<double> means, inv_vars, norm, logw;
-  // EM tying (accumulator rows)
-  DevBuf<uint32_t> dens_mean, dens_var;
-  std::vector<uint32_t> h_dens_off;
-  // host copies of the finalised tables: the kernel-specific packings are built on first use of that kernel
-  std::vector<double> h_means, h_inv_vars, h_norm, h_logw;
-  bool mfma_packed = false, pf_packed = false;
-  uint32_t n_mean = 0, n_var = 0;
-  // MFMA packing
-  int ksteps = 0;
-  uint32_t n_blocks = 0, n_groups = 0;
-  DevBuf<double> apack;
-  DevBuf<uint32_t> blk_meta, grp_state;
-  std::vector<uint32_t> group_first_block;  // host: [n_groups+1]
-  DevBuf<uint32_t> split_begin;
-  uint32_t split_ny = 0;
-  // fp16 prefilter + FP64 refinement (gmm_prefilter.hip); pf_ks32 == 0: model not eligible
-  int pf_ks32 = 0;
-  uint32_t pf_groups = 0, pf_ny = 0, max_dens = 0, pf_slots = 0, pf_chunks = 1, pf_pstates = 0;
-  DevBuf<unsigned char> pf_apack;
-  DevBuf<float> pf_anorm, featsT;
-  DevBuf<uint32_t> pf_split, pf_mask, pf_ndens, pf_ring;
-  DevBuf<double> pf_rows;
-  DevBuf<unsigned long long> pf_counter;
-  // streams / workspace
-  hipStream_t s_gmm = nullptr, s_search = nullptr;
-  DevBuf<double> scores[2];
-  hipEvent_t ev_scored[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
-  size_t chunk_frames = 0;
-  bool overlap = true;  // search of chunk i on its own stream while chunk i+1 is scored (SRGPU_OVERLAP=0: one stream)
-  // profiling
-  bool profiling = false;
-  std::vector<EventPair> events;
-  sr_profile prof{};
-};
-
-struct sr_corpus {
-  sr_model* model = nullptr;
-  uint32_t n_utts = 0;
-  uint64_t n_frames = 0;
-  std::vector<uint64_t> frame_off;  // host copy
-  DevBuf<float> feats;
-  DevBuf<uint64_t> d_frame_off;
-  // search outputs (device)
-  DevBuf<double> tb_score;
-  DevBuf<uint16_t> tb_word, tb_bkp;
-  DevBuf<uint32_t> out_words, out_count, out_flags;
-  // aligner workspace
-  DevBuf<uint16_t> automata, out_states;
-  DevBuf<uint64_t> aut_off, bp_off, al_blk_frame0;
-  DevBuf<uint32_t> al_list_off, al_states, al_blk_frames, al_blk_list;
-  DevBuf<uint8_t> backptr;
-  DevBuf<double> out_cost, path_scores;
-  // EM accumulation workspace
-  DevBuf<uint64_t> pair_off;
-  DevBuf<uint32_t> pair_frame, key_mean, key_var, iota, keys_sorted, pairs_sorted, row_begin;
-  DevBuf<double> pair_w, acc_mean, acc_var, w_mean, w_var;
-  DevBuf<unsigned char> sort_temp;
-};
-
-struct sr_lexicon {
-  sr_model* model = nullptr;
-  uint32_t n_words = 0, n_slots = 0, silence_idx = 0, silence_state = 0;
-  double tdp[3] = {0, 0, 0};
-  DevBuf<uint32_t> slot_info, slot_word, word_end_slot;
-  // type-sorted copy for the fast kernel
-  DevBuf<uint32_t> f_state, f_pred, f_orig, f_type, f_word;
-  uint32_t f_n = 0, f_init = 0, f_init_end = 0;
-};
-
-struct sr_bigram {
-  sr_model* model = nullptr;
-  uint32_t n_words = 0, silence = 0, n_positions = 0;
-  float tdp[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-  DevBuf<uint32_t> slot_off, slot_mix;
-  DevBuf<uint16_t> mixtures;
-  DevBuf<float> lmT, lm_rowmin, lm_rowmax;
-  // workspace
-  DevBuf<uint32_t> we_slot, we_bp, out_word, out_time, out_count, out_flags;
-  DevBuf<float> we_score, out_score;
-  DevBuf<uint4> book;
-  DevBuf<uint64_t> book_off;
-};
 
 namespace {
 
@@ -525,6 +399,9 @@ int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm
 struct Chunk { uint32_t u0, u1; uint64_t f0, f1; };
 std::vector<Chunk> make_chunks(const sr_corpus* c, size_t chunk_frames) {
   std::vector<Chunk> out;
+  // While the feeder is still copying (sr_corpus_upload_async) the corpus is cut into at least four chunks, so that the
+  // first is scored as soon as its pieces have landed and the rest of the transfer hides behind it.
+  if (srhost::corpus_upload_in_flight(c)) chunk_frames = std::min<size_t>(chunk_frames, std::max<size_t>(1, (size_t)(c->n_frames / 4 + 1)));
   uint32_t u = 0;
   while (u < c->n_utts) {
     uint32_t v = u + 1;
@@ -710,6 +587,7 @@ int sr_corpus_upload(sr_model* m, const float* feats, const uint64_t* frame_off,
 int sr_corpus_destroy(sr_corpus* c) {
   return guarded(__func__, [&]() -> int {
   if (!c) return SR_OK;
+  srhost::feeder_join(c);  // an upload still in flight borrows the caller's buffer and writes into c->feats
   if (c->model) { (void)hipSetDevice(c->model->device); (void)hipDeviceSynchronize(); }
   c->feats.release(); c->d_frame_off.release(); c->tb_score.release(); c->tb_word.release(); c->tb_bkp.release();
   c->out_words.release(); c->out_count.release(); c->out_flags.release(); c->automata.release(); c->out_states.release();
@@ -735,6 +613,7 @@ int sr_score_corpus(sr_model* m, sr_corpus* c, int gmm_kernel, double* out) {
   HIP_TRY(m->scores[0].ensure((size_t)std::min<uint64_t>(F, step) * m->ld));
   for (uint64_t f = 0; f < F; f += step) {
     const uint64_t n = std::min<uint64_t>(step, F - f);
+    if ((rc = srhost::corpus_ready(c, f, f + n, m->s_gmm))) return rc;
     if ((rc = launch_scoring(m, c->feats.p + f * m->dim, n, gmm_kernel, m->scores[0].p))) return rc;
     HIP_TRY(hipStreamSynchronize(m->s_gmm));
     HIP_TRY(hipMemcpy2D(out + f * m->n_states, (size_t)m->n_states * sizeof(double), m->scores[0].p,
@@ -909,6 +788,7 @@ int sr_recognize_corpus(sr_model* m, sr_corpus* c, sr_lexicon* l, const sr_searc
     const Chunk& ch = chunks[i];
     const int buf = (int)(i & 1);
     if (i >= 2) HIP_TRY(hipStreamWaitEvent(m->s_gmm, m->ev_consumed[buf], 0));
+    if ((rc = srhost::corpus_ready(c, ch.f0, ch.f1, m->s_gmm))) return rc;
     if ((rc = launch_scoring(m, c->feats.p + ch.f0 * m->dim, ch.f1 - ch.f0, p->gmm_kernel, m->scores[buf].p))) return rc;
     HIP_TRY(hipEventRecord(m->ev_scored[buf], m->s_gmm));
     HIP_TRY(hipStreamWaitEvent(s_search, m->ev_scored[buf], 0));
@@ -1054,6 +934,7 @@ int sr_recognize_bigram_corpus(sr_model* m, sr_corpus* c, sr_bigram* b, const sr
     const Chunk& ch = chunks[i];
     const int buf = (int)(i & 1);
     if (i >= 2) HIP_TRY(hipStreamWaitEvent(m->s_gmm, m->ev_consumed[buf], 0));
+    if ((rc = srhost::corpus_ready(c, ch.f0, ch.f1, m->s_gmm))) return rc;
     if ((rc = launch_scoring(m, c->feats.p + ch.f0 * m->dim, ch.f1 - ch.f0, p->gmm_kernel, m->scores[buf].p))) return rc;
     HIP_TRY(hipEventRecord(m->ev_scored[buf], m->s_gmm));
     HIP_TRY(hipStreamWaitEvent(s_search, m->ev_scored[buf], 0));
@@ -1094,8 +975,10 @@ int sr_recognize_bigram_corpus(sr_model* m, sr_corpus* c, sr_bigram* b, const sr
 int sr_recognize_batch(sr_model* m, sr_lexicon* l, const sr_search_params* p, const float* feats,
                        const uint64_t* frame_off, uint32_t n_utts, uint32_t* out_words, uint64_t* out_word_off) {
   return guarded(__func__, [&]() -> int {
+  // the feeder copies while the first chunks are being scored (feeder.cpp); the corpus goes away with `own`, which also
+  // ends the borrowing of the caller's buffer
   sr_corpus* c = nullptr;
-  int rc = sr_corpus_upload(m, feats, frame_off, n_utts, &c);
+  int rc = sr_corpus_upload_async(m, feats, frame_off, n_utts, &c);
   if (rc) return rc;
   std::unique_ptr<sr_corpus, int (*)(sr_corpus*)> own(c, sr_corpus_destroy);
   return sr_recognize_corpus(m, c, l, p, out_words, out_word_off, nullptr, nullptr, nullptr);
@@ -1170,6 +1053,7 @@ static int align_common(sr_model* m, sr_corpus* c, const uint16_t* automata, con
     const Chunk& ch = chunks[i];
     const int buf = (int)(i & 1);
     if (i >= 2) HIP_TRY(hipStreamWaitEvent(m->s_gmm, m->ev_consumed[buf], 0));
+    if ((rc = srhost::corpus_ready(c, ch.f0, ch.f1, m->s_gmm))) return rc;
     if (listed) {
       GmmExactArgs ga{};
       ga.feats = c->feats.p; ga.n_frames = c->n_frames; ga.dim = m->dim; ga.n_states = m->n_states;
@@ -1231,6 +1115,7 @@ int sr_path_scores_corpus(sr_model* m, sr_corpus* c, const uint16_t* states, int
   if (!states || !out) return fail(SR_EINVAL, "null argument");
   for (uint64_t f = 0; f < F; f++)
     if (states[f] >= m->n_states) return fail(SR_EINVAL, "frame %llu: state %u >= n_states", (unsigned long long)f, states[f]);
+  if ((rc = srhost::corpus_ready(c, 0, F, m->s_gmm))) return rc;
   HIP_TRY(c->out_states.upload(states, F));
   HIP_TRY(c->path_scores.ensure(F));
   if (gmm_kernel != SR_GMM_MFMA) {  // bit-exact kernels: score the F (frame, state) pairs directly, no dense table
@@ -1307,6 +1192,7 @@ int sr_accumulate_corpus(sr_model* m, sr_corpus* c, const uint16_t* states, int 
   }
   if (n_pairs >= (1ull << 31)) return fail(SR_ELIMIT, "too many (frame, density) pairs");
   if (n_pairs == 0) return SR_OK;
+  if ((rc = srhost::corpus_ready(c, 0, F, m->s_gmm))) return rc;
   HIP_TRY(c->out_states.upload(states, F));
   HIP_TRY(c->pair_off.upload(pair_off.data(), F));
   HIP_TRY(c->pair_frame.ensure(n_pairs)); HIP_TRY(c->key_mean.ensure(n_pairs)); HIP_TRY(c->key_var.ensure(n_pairs));

@@ -105,6 +105,16 @@ int main(int argc, char** argv) {
       }
       printf("stats %u %u %u %u %zu %zu\n", st.errors.total_count, st.errors.substitute_count, st.errors.insert_count,
              st.errors.delete_count, st.ref_words, st.sentence_errors);
+      // the same corpus sharded over device handles (here: three replicas on device 0, the recogniser's own + two more)
+      {
+        sr::RecognitionStats st3 = rec.recognize(corpus, std::vector<int>{0, 0, 0});
+        bool same = st3.hypotheses == st.hypotheses && st3.errors.total_count == st.errors.total_count;
+        uint64_t frames = 0;
+        for (uint64_t f : st3.frames_per_device) frames += f;
+        printf("multi %s %zu %llu\n", same ? "same" : "DIFFERENT", st3.frames_per_device.size(), (unsigned long long)frames);
+        sr::RecognitionStats st3b = rec.recognize(corpus, std::vector<int>{0, 0, 0});  // replicas are kept and reused
+        printf("multi_again %s\n", st3b.hypotheses == st.hypotheses ? "same" : "DIFFERENT");
+      }
       // single-sequence entry points on utterance 0
       std::vector<sr::WordIdx> one;
       rec.recognizeSequence_pruned(feats[0].data(), feats[0].size() / dim, one);

@@ -125,3 +125,23 @@ def test_build_stamps_follow_content_not_mtime(built_lib):
     before = os.path.getmtime(obj)
     build.build()
     assert os.path.getmtime(obj) == before and open(build.LIB + ".stamp").read() == lib_stamp
+
+
+def test_shard_utterances_matches_the_python_helper(built_lib):
+    """sr_shard_utterances (the C ABI's LPT deal, used by sr_recognize_batch_multi) == sharding.shard_utterances (used by
+    bench.py's ranks): same shards, so an in-process multi-device run and a one-process-per-GPU run decode the same
+    utterances on the same device index."""
+    from speechrecognition_amd import capi, sharding
+    rng = np.random.default_rng(3)
+    for n_utts, n_shards in ((0, 3), (1, 4), (17, 2), (1000, 8), (257, 5), (64, 64)):
+        lens = rng.integers(1, 400, size=n_utts)
+        if n_utts > 10:
+            lens[3:9] = 77  # ties
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        shard_of, load = capi.shard_utterances(off, n_shards)
+        want = sharding.shard_utterances(off, n_shards)
+        for r in range(n_shards):
+            assert np.array_equal(np.nonzero(shard_of == r)[0], want[r]), (n_utts, n_shards, r)
+            assert int(load[r]) == int(lens[want[r]].sum()) if n_utts else int(load[r]) == 0
+    with pytest.raises(capi.SrError):
+        capi.shard_utterances(np.array([0, 5], np.uint64), 0)

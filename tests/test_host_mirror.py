@@ -88,6 +88,9 @@ def test_recognizer_and_aligner_mirror_on_gpu(driver, tmp_path, oracle_lib, kern
         tot += o.edit_distance(r, np.asarray(h, dtype=np.uint64)).astype(np.int64)
     stats = [int(x) for x in [l for l in out if l.startswith("stats")][0].split()[1:]]
     assert stats[:4] == list(tot) and stats[4] == sum(len(r) for r in refs)
+    multi = [l for l in out if l.startswith("multi ")][0].split()
+    assert multi[1] == "same" and multi[2] == "3" and int(multi[3]) == sum(len(x) for x in utts)
+    assert [l for l in out if l.startswith("multi_again")][0].split()[1] == "same"
     one = [int(x) for x in [l for l in out if l.startswith("one")][0].split()[1:]]
     assert one == hyps[0]
     sc = o.score_matrix(utts[0])
