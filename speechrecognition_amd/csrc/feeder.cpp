@@ -41,6 +41,7 @@ struct sr_feeder {
   hipStream_t s_copy = nullptr;
   float* staging[2] = {nullptr, nullptr};
   hipEvent_t staging_free[2] = {nullptr, nullptr};
+  sr_model* lender = nullptr;  // the stream, buffers and events above are the model's (returned at the end), else our own
   int device = 0;
   float* dst = nullptr;
 };
@@ -95,11 +96,16 @@ void feeder_free(sr_feeder* fd) {
   if (fd->thread.joinable()) fd->thread.join();
   (void)hipSetDevice(fd->device);
   for (hipEvent_t ev : fd->done) if (ev) (void)hipEventDestroy(ev);
-  for (int b = 0; b < 2; b++) {
-    if (fd->staging_free[b]) (void)hipEventDestroy(fd->staging_free[b]);
-    if (fd->staging[b]) (void)hipHostFree(fd->staging[b]);
+  if (fd->lender) {
+    if (fd->s_copy) (void)hipStreamSynchronize(fd->s_copy);
+    fd->lender->staging_busy.store(false);
+  } else {
+    for (int b = 0; b < 2; b++) {
+      if (fd->staging_free[b]) (void)hipEventDestroy(fd->staging_free[b]);
+      if (fd->staging[b]) (void)hipHostFree(fd->staging[b]);
+    }
+    if (fd->s_copy) (void)hipStreamDestroy(fd->s_copy);
   }
-  if (fd->s_copy) (void)hipStreamDestroy(fd->s_copy);
   delete fd;
 }
 
@@ -138,12 +144,27 @@ int corpus_from_segments(sr_model* m, std::vector<Segment> segments, const uint6
   fd->piece_floats = kPieceBytes / sizeof(float);
   fd->n_pieces = (uint32_t)((total + fd->piece_floats - 1) / fd->piece_floats);
   fd->done.assign(fd->n_pieces, nullptr);
-  if ((e = hipStreamCreateWithFlags(&fd->s_copy, hipStreamNonBlocking)) != hipSuccess)
-    return fail(SR_EHIP, "hipStreamCreate (feeder): %s", hipGetErrorString(e));
-  for (int b = 0; b < 2; b++)
-    if ((e = hipHostMalloc(reinterpret_cast<void**>(&fd->staging[b]), std::min<uint64_t>(kPieceBytes, total * sizeof(float)), hipHostMallocDefault)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&fd->staging_free[b], hipEventDisableTiming)) != hipSuccess)
-      return fail(SR_EHIP, "pinned staging buffer: %s", hipGetErrorString(e));
+  // the model keeps one set of feeder resources (copy stream, two pinned 8 MiB buffers); a second upload that overlaps the
+  // first gets its own
+  bool expected = false;
+  if (m->staging_busy.compare_exchange_strong(expected, true)) {
+    fd->lender = m;
+    if (!m->s_copy && (e = hipStreamCreateWithFlags(&m->s_copy, hipStreamNonBlocking)) != hipSuccess)
+      return fail(SR_EHIP, "hipStreamCreate (feeder): %s", hipGetErrorString(e));
+    for (int b = 0; b < 2; b++)
+      if ((!m->staging[b] && (e = hipHostMalloc(reinterpret_cast<void**>(&m->staging[b]), kPieceBytes, hipHostMallocDefault)) != hipSuccess) ||
+          (!m->staging_free[b] && (e = hipEventCreateWithFlags(&m->staging_free[b], hipEventDisableTiming)) != hipSuccess))
+        return fail(SR_EHIP, "pinned staging buffer: %s", hipGetErrorString(e));
+    fd->s_copy = m->s_copy;
+    for (int b = 0; b < 2; b++) { fd->staging[b] = m->staging[b]; fd->staging_free[b] = m->staging_free[b]; }
+  } else {
+    if ((e = hipStreamCreateWithFlags(&fd->s_copy, hipStreamNonBlocking)) != hipSuccess)
+      return fail(SR_EHIP, "hipStreamCreate (feeder): %s", hipGetErrorString(e));
+    for (int b = 0; b < 2; b++)
+      if ((e = hipHostMalloc(reinterpret_cast<void**>(&fd->staging[b]), std::min<uint64_t>(kPieceBytes, total * sizeof(float)), hipHostMallocDefault)) != hipSuccess ||
+          (e = hipEventCreateWithFlags(&fd->staging_free[b], hipEventDisableTiming)) != hipSuccess)
+        return fail(SR_EHIP, "pinned staging buffer: %s", hipGetErrorString(e));
+  }
   for (uint32_t i = 0; i < fd->n_pieces; i++)
     if ((e = hipEventCreateWithFlags(&fd->done[i], hipEventDisableTiming)) != hipSuccess)
       return fail(SR_EHIP, "hipEventCreate (feeder): %s", hipGetErrorString(e));

@@ -6,6 +6,8 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -78,16 +80,22 @@ struct sr_model {
   DevBuf<double> apack;
   DevBuf<uint32_t> blk_meta, grp_state;
   std::vector<uint32_t> group_first_block;  // host: [n_groups+1]
-  DevBuf<uint32_t> split_begin;
+  std::map<uint32_t, std::unique_ptr<DevBuf<uint32_t>>> split_tabs, pf_split_tabs;  // state-range split tables by split count
+  const uint32_t *split_cur = nullptr, *pf_split_cur = nullptr;
   uint32_t split_ny = 0;
   // fp16 prefilter + FP64 refinement (gmm_prefilter.hip); pf_ks32 == 0: model not eligible
   int pf_ks32 = 0;
   uint32_t pf_groups = 0, pf_ny = 0, max_dens = 0, pf_slots = 0, pf_chunks = 1, pf_pstates = 0;
   DevBuf<unsigned char> pf_apack;
   DevBuf<float> pf_anorm, featsT;
-  DevBuf<uint32_t> pf_split, pf_mask, pf_ndens, pf_ring;
+  DevBuf<uint32_t> pf_mask, pf_ndens, pf_ring;
   DevBuf<double> pf_rows;
   DevBuf<unsigned long long> pf_counter;
+  // feeder resources (feeder.cpp), created by the first asynchronous upload and kept: pinning 2 x 8 MiB costs milliseconds
+  hipStream_t s_copy = nullptr;
+  float* staging[2] = {nullptr, nullptr};
+  hipEvent_t staging_free[2] = {nullptr, nullptr};
+  std::atomic<bool> staging_busy{false};
   // streams / workspace
   hipStream_t s_gmm = nullptr, s_search = nullptr;
   DevBuf<double> scores[2];

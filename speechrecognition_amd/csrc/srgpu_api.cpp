@@ -268,11 +268,16 @@ int set_prefilter_splits(sr_model* m, uint32_t nx) {
   ny = std::max(1u, std::min(ny, std::max(1u, m->pf_groups / 8)));
   if (const char* e = getenv("SRGPU_PF_NY")) ny = std::max(1u, std::min((uint32_t)atoi(e), m->pf_groups));
   if (ny >= 8) ny &= ~7u;
-  if (ny == m->pf_ny) return SR_OK;
-  std::vector<uint32_t> sb(ny + 1);
-  for (uint32_t y = 0; y <= ny; y++) sb[y] = (uint32_t)((uint64_t)m->pf_groups * y / ny);
-  HIP_TRY(hipStreamSynchronize(m->s_gmm));
-  HIP_TRY(m->pf_split.upload(sb.data(), sb.size()));
+  // one table per split count, kept: launches of different sizes (the pieces of a corpus that is still being fed) alternate
+  // between them without touching a table a queued kernel may still read
+  std::unique_ptr<DevBuf<uint32_t>>& tab = m->pf_split_tabs[ny];
+  if (!tab) {
+    std::vector<uint32_t> sb(ny + 1);
+    for (uint32_t y = 0; y <= ny; y++) sb[y] = (uint32_t)((uint64_t)m->pf_groups * y / ny);
+    tab.reset(new DevBuf<uint32_t>());
+    HIP_TRY(tab->upload(sb.data(), sb.size()));
+  }
+  m->pf_split_cur = tab->p;
   m->pf_ny = ny;
   return SR_OK;
 }
@@ -286,18 +291,21 @@ int set_splits(sr_model* m, uint32_t nx) {
   uint32_t ny = (target_wgs + nx - 1) / std::max(1u, nx);
   ny = std::max(1u, std::min(ny, std::min(m->n_groups, std::max(1u, m->n_blocks / 32))));
   if (ny >= 8) ny &= ~7u;  // multiples of 8 enable the XCD-aware tile map
-  if (ny == m->split_ny) return SR_OK;
-  std::vector<uint32_t> sb(ny + 1);
-  for (uint32_t y = 0; y <= ny; y++) {
-    // balance by blocks, cut at group boundaries
-    const uint64_t want = (uint64_t)m->n_blocks * y / ny;
-    auto it = std::lower_bound(m->group_first_block.begin(), m->group_first_block.end(), (uint32_t)want);
-    sb[y] = *it;
+  std::unique_ptr<DevBuf<uint32_t>>& tab = m->split_tabs[ny];  // (kept per split count, see set_prefilter_splits)
+  if (!tab) {
+    std::vector<uint32_t> sb(ny + 1);
+    for (uint32_t y = 0; y <= ny; y++) {
+      // balance by blocks, cut at group boundaries
+      const uint64_t want = (uint64_t)m->n_blocks * y / ny;
+      auto it = std::lower_bound(m->group_first_block.begin(), m->group_first_block.end(), (uint32_t)want);
+      sb[y] = *it;
+    }
+    sb[0] = 0;
+    sb[ny] = m->n_blocks;
+    tab.reset(new DevBuf<uint32_t>());
+    HIP_TRY(tab->upload(sb.data(), sb.size()));
   }
-  sb[0] = 0;
-  sb[ny] = m->n_blocks;
-  HIP_TRY(hipStreamSynchronize(m->s_gmm));
-  HIP_TRY(m->split_begin.upload(sb.data(), sb.size()));
+  m->split_cur = tab->p;
   m->split_ny = ny;
   return SR_OK;
 }
@@ -317,10 +325,9 @@ int prof_end(sr_model* m, hipStream_t s, EventPair* ep) {
   return SR_OK;
 }
 
-// score frames [f_begin, f_end) of `feats` into `out` (device, row stride m->ld) on stream s_gmm
-int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm_kernel, double* d_out) {
-  if (n_frames == 0) return SR_OK;
-  EventPair ep{};
+// kernel-specific model packing (first use) and workspaces for scoring launches of up to n_max frames: growing a
+// workspace frees the old one, which must not happen between launches that are still queued
+int reserve_scoring(sr_model* m, int gmm_kernel, uint64_t n_max) {
   if (gmm_kernel == SR_GMM_MFMA && !m->mfma_packed) {
     int rc = pack_model(m, m->h_dens_off.data(), m->h_means.data(), m->h_inv_vars.data(), m->h_norm.data(), m->h_logw.data());
     if (rc) return rc;
@@ -331,6 +338,28 @@ int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm
     if (rc) return rc;
     m->pf_packed = true;
   }
+  if (gmm_kernel == SR_GMM_PREFILTER && m->pf_ks32 > 0 && n_max > 0) {
+    const uint64_t ldT = (n_max + 63) & ~(uint64_t)63;
+    const size_t want_T = (size_t)ldT * m->dim, want_mask = (size_t)((m->pf_groups + 1u) & ~1u) * n_max * 4;
+    GmmRefineArgs ra{};
+    ra.n_frames = n_max; ra.dim = m->dim; ra.n_pstates = m->pf_pstates; ra.n_slots = m->pf_slots;
+    const size_t want_ring = gmm_refine_ring_words(ra);
+    if (want_T > m->featsT.n || want_mask > m->pf_mask.n || want_ring > m->pf_ring.n) HIP_TRY(hipStreamSynchronize(m->s_gmm));
+    HIP_TRY(m->featsT.ensure(want_T));
+    HIP_TRY(m->pf_mask.ensure(want_mask));  // the refinement reads group pairs
+    HIP_TRY(m->pf_ring.ensure(want_ring));
+  }
+  return SR_OK;
+}
+
+// score frames [f_begin, f_end) of `feats` into `out` (device, row stride m->ld) on stream s_gmm
+int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm_kernel, double* d_out) {
+  if (n_frames == 0) return SR_OK;
+  EventPair ep{};
+  {
+    int rc = reserve_scoring(m, gmm_kernel, n_frames);
+    if (rc) return rc;
+  }
   if (gmm_kernel == SR_GMM_MFMA) {
     const uint32_t tile = gmm_mfma_frames_per_tile(m->ksteps);
     const uint32_t nx = (uint32_t)((n_frames + tile - 1) / tile);
@@ -338,7 +367,7 @@ int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm
     if (rc) return rc;
     GmmMfmaArgs a{};
     a.feats = d_feats; a.n_frames = n_frames; a.dim = m->dim;
-    a.apack = m->apack.p; a.blk_meta = m->blk_meta.p; a.grp_state = m->grp_state.p; a.split_begin = m->split_begin.p;
+    a.apack = m->apack.p; a.blk_meta = m->blk_meta.p; a.grp_state = m->grp_state.p; a.split_begin = m->split_cur;
     a.out = d_out; a.ld = m->ld; a.nx = nx; a.ny = m->split_ny;
     if ((rc = prof_begin(m, m->s_gmm, 0, &ep))) return rc;
     HIP_TRY(launch_gmm_mfma(a, m->ksteps, !m->max_approx, m->s_gmm));
@@ -349,18 +378,15 @@ int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm
     int rc = set_prefilter_splits(m, nx);
     if (rc) return rc;
     const uint64_t ldT = (n_frames + 63) & ~(uint64_t)63;
-    HIP_TRY(m->featsT.ensure((size_t)ldT * m->dim));
-    HIP_TRY(m->pf_mask.ensure((size_t)((m->pf_groups + 1u) & ~1u) * n_frames * 4));  // the refinement reads group pairs
     GmmPrefilterArgs pa{};
     pa.feats = d_feats; pa.n_frames = n_frames; pa.dim = m->dim;
-    pa.apack = m->pf_apack.p; pa.grp_anorm = m->pf_anorm.p; pa.split_begin = m->pf_split.p;
+    pa.apack = m->pf_apack.p; pa.grp_anorm = m->pf_anorm.p; pa.split_begin = m->pf_split_cur;
     pa.mask = m->pf_mask.p; pa.nx = nx; pa.ny = m->pf_ny; pa.chunks = m->pf_chunks;
     GmmRefineArgs ra{};
     ra.feats = d_feats; ra.featsT = m->featsT.p; ra.n_frames = n_frames; ra.n_frames_ld = ldT; ra.dim = m->dim; ra.n_pstates = m->pf_pstates; ra.chunks = m->pf_chunks;
     ra.n_dens_ps = m->pf_ndens.p; ra.rows = m->pf_rows.p; ra.n_slots = m->pf_slots;
     ra.mask = m->pf_mask.p; ra.out = d_out; ra.ld = m->ld;
     ra.n_refined = m->profiling ? m->pf_counter.p : nullptr;
-    HIP_TRY(m->pf_ring.ensure(gmm_refine_ring_words(ra)));
     ra.ring = m->pf_ring.p;
     if (m->profiling) m->prof.refined_pairs += n_frames * (uint64_t)m->n_states;
     EventPair ep_p{}, ep_r{};
@@ -399,9 +425,7 @@ int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm
 struct Chunk { uint32_t u0, u1; uint64_t f0, f1; };
 std::vector<Chunk> make_chunks(const sr_corpus* c, size_t chunk_frames) {
   std::vector<Chunk> out;
-  // While the feeder is still copying (sr_corpus_upload_async) the corpus is cut into at least four chunks, so that the
-  // first is scored as soon as its pieces have landed and the rest of the transfer hides behind it.
-  if (srhost::corpus_upload_in_flight(c)) chunk_frames = std::min<size_t>(chunk_frames, std::max<size_t>(1, (size_t)(c->n_frames / 4 + 1)));
+
   uint32_t u = 0;
   while (u < c->n_utts) {
     uint32_t v = u + 1;
@@ -410,6 +434,26 @@ std::vector<Chunk> make_chunks(const sr_corpus* c, size_t chunk_frames) {
     u = v;
   }
   return out;
+}
+
+// Scores frames [f0, f1) of the corpus into `table` (row 0 = frame f0).  While the feeder is still copying
+// (sr_corpus_upload_async) the range is scored in three launches -- the first sixth, up to the half, the rest -- each
+// waiting on the device only for its own pieces: scoring starts ~1 ms into the transfer and the rest of it hides behind
+// the kernels (the feeder delivers 5-10 GB/s, scoring consumes 2 GB/s of features).  The search that follows sees one table.
+int score_chunk(sr_model* m, sr_corpus* c, uint64_t f0, uint64_t f1, int gmm_kernel, double* table) {
+  const uint64_t n = f1 - f0;
+  uint64_t cuts[3] = {f1, f1, f1};
+  int n_cuts = 1;
+  if (srhost::corpus_upload_in_flight(c) && n >= 6 * 4096) { cuts[0] = f0 + n / 6; cuts[1] = f0 + n / 2; n_cuts = 3; }
+  int rc = reserve_scoring(m, gmm_kernel, n_cuts == 3 ? n - n / 2 : n);
+  if (rc) return rc;
+  uint64_t a = f0;
+  for (int i = 0; i < n_cuts; i++) {
+    if ((rc = srhost::corpus_ready(c, a, cuts[i], m->s_gmm))) return rc;
+    if ((rc = launch_scoring(m, c->feats.p + a * m->dim, cuts[i] - a, gmm_kernel, table + (a - f0) * m->ld))) return rc;
+    a = cuts[i];
+  }
+  return SR_OK;
 }
 
 int ensure_score_ws(sr_model* m, const std::vector<Chunk>& chunks) {
@@ -531,12 +575,17 @@ int sr_model_destroy(sr_model* m) {
   for (auto& ep : m->events) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
   m->dens_mean.release(); m->dens_var.release();
   m->dens_off.release(); m->means.release(); m->inv_vars.release(); m->norm.release(); m->logw.release();
-  m->apack.release(); m->blk_meta.release(); m->grp_state.release(); m->split_begin.release();
+  m->apack.release(); m->blk_meta.release(); m->grp_state.release();
   m->scores[0].release(); m->scores[1].release();
   for (int i = 0; i < 2; i++) {
     if (m->ev_scored[i]) (void)hipEventDestroy(m->ev_scored[i]);
     if (m->ev_consumed[i]) (void)hipEventDestroy(m->ev_consumed[i]);
   }
+  for (int b = 0; b < 2; b++) {
+    if (m->staging_free[b]) (void)hipEventDestroy(m->staging_free[b]);
+    if (m->staging[b]) (void)hipHostFree(m->staging[b]);
+  }
+  if (m->s_copy) (void)hipStreamDestroy(m->s_copy);
   if (m->s_gmm) (void)hipStreamDestroy(m->s_gmm);
   if (m->s_search) (void)hipStreamDestroy(m->s_search);
   delete m;
@@ -788,8 +837,7 @@ int sr_recognize_corpus(sr_model* m, sr_corpus* c, sr_lexicon* l, const sr_searc
     const Chunk& ch = chunks[i];
     const int buf = (int)(i & 1);
     if (i >= 2) HIP_TRY(hipStreamWaitEvent(m->s_gmm, m->ev_consumed[buf], 0));
-    if ((rc = srhost::corpus_ready(c, ch.f0, ch.f1, m->s_gmm))) return rc;
-    if ((rc = launch_scoring(m, c->feats.p + ch.f0 * m->dim, ch.f1 - ch.f0, p->gmm_kernel, m->scores[buf].p))) return rc;
+    if ((rc = score_chunk(m, c, ch.f0, ch.f1, p->gmm_kernel, m->scores[buf].p))) return rc;
     HIP_TRY(hipEventRecord(m->ev_scored[buf], m->s_gmm));
     HIP_TRY(hipStreamWaitEvent(s_search, m->ev_scored[buf], 0));
     da.scores = m->scores[buf].p; da.frame_base = ch.f0; da.utt_first = ch.u0; da.n_utts = ch.u1 - ch.u0;
@@ -934,8 +982,7 @@ int sr_recognize_bigram_corpus(sr_model* m, sr_corpus* c, sr_bigram* b, const sr
     const Chunk& ch = chunks[i];
     const int buf = (int)(i & 1);
     if (i >= 2) HIP_TRY(hipStreamWaitEvent(m->s_gmm, m->ev_consumed[buf], 0));
-    if ((rc = srhost::corpus_ready(c, ch.f0, ch.f1, m->s_gmm))) return rc;
-    if ((rc = launch_scoring(m, c->feats.p + ch.f0 * m->dim, ch.f1 - ch.f0, p->gmm_kernel, m->scores[buf].p))) return rc;
+    if ((rc = score_chunk(m, c, ch.f0, ch.f1, p->gmm_kernel, m->scores[buf].p))) return rc;
     HIP_TRY(hipEventRecord(m->ev_scored[buf], m->s_gmm));
     HIP_TRY(hipStreamWaitEvent(s_search, m->ev_scored[buf], 0));
     ba.scores = m->scores[buf].p; ba.frame_base = ch.f0; ba.utt_first = ch.u0; ba.n_utts = ch.u1 - ch.u0;

@@ -1,5 +1,7 @@
-"""PCIe-inclusive rate at the boundary that hands over host buffers: upload (sr_corpus_upload) + recognise + destroy per
-step, against the resident-features rate bench.py reports.  usage: python tools/time_batch_boundary.py"""
+"""PCIe-inclusive rate at the boundary that hands over host buffers, against the resident-features rate bench.py reports:
+(a) sr_corpus_upload (blocking copy of pageable memory) + recognise + destroy per step, (b) sr_recognize_batch, which feeds
+through sr_corpus_upload_async (pinned staging on a copy stream, scoring starts on the first chunk while the rest is in flight).
+usage: python tools/time_batch_boundary.py"""
 import os, sys, tempfile, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -23,12 +25,19 @@ with capi.Model.from_mixset(mp, 39) as m:
     for _ in range(3):
         host_step()
     t_host = (time.perf_counter() - t0) / 3
+    m.recognize_batch(lexh, feats, off, 200.0, 10.0)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        wb, ob = m.recognize_batch(lexh, feats, off, 200.0, 10.0)
+    t_batch = (time.perf_counter() - t0) / 3
     c = m.upload(feats, off)
     c.recognize(lexh, 200.0, 10.0)
     t0 = time.perf_counter()
     for _ in range(3):
-        c.recognize(lexh, 200.0, 10.0)
+        wr, orr = c.recognize(lexh, 200.0, 10.0)
     t_res = (time.perf_counter() - t0) / 3
+    assert np.array_equal(wb, wr) and np.array_equal(ob, orr)
     c.close(); lexh.close()
 print(f"resident features: {t_res*1e3:.1f} ms/step = {len(feats)/t_res:,.0f} frames/s; "
-      f"host buffers (47 MB pageable H2D + alloc/free per step): {t_host*1e3:.1f} ms/step = {len(feats)/t_host:,.0f} frames/s")
+      f"host buffers, blocking upload (47 MB pageable H2D + alloc/free per step): {t_host*1e3:.1f} ms/step = {len(feats)/t_host:,.0f} frames/s; "
+      f"host buffers, sr_recognize_batch (asynchronous feeder, scoring starts on the first sixth): {t_batch*1e3:.1f} ms/step = {len(feats)/t_batch:,.0f} frames/s")
