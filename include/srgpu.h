@@ -182,6 +182,10 @@ SR_API int sr_path_scores_corpus(sr_model* m, sr_corpus* c, const uint16_t* stat
  * sr_model_load_mixset installs the file's own; models from sr_model_create default to one row per density. */
 SR_API int sr_model_set_tying(sr_model* m, uint32_t n_mean, uint32_t n_var, const uint32_t* dens_mean, const uint32_t* dens_var);
 SR_API int sr_model_tying_info(const sr_model* m, uint32_t* n_mean, uint32_t* n_var);
+/* The topology a trainer needs to turn sr_accumulate_corpus' statistics into a MIXSET file (sr_mixset_write) or the next model
+ * (sr_model_create_from_statistics): dens_off[n_states + 1], and the accumulator rows dens_mean[C], dens_var[C] of every density
+ * in mixture order (MixtureModel::mixtures_, Mixtures.hpp:88).  Any pointer may be NULL. */
+SR_API int sr_model_topology(const sr_model* m, uint32_t* dens_off, uint32_t* dens_mean, uint32_t* dens_var);
 /* states[total_frames]: aligned mixture per frame (an alignment from sr_align_corpus*).  first_pass: density 0 of
  * the mixture gets every frame; else max_approx: the arg-min density; else soft memberships.  Outputs (host):
  * mean_acc[n_mean*dim], mean_w[n_mean], var_acc[n_var*dim] (starts at 1e-4 like the reference), var_w[n_var].

@@ -7,7 +7,8 @@
 //   GpuMixtureScorer : FeatureScorer     plug-in for `"feature-scorer": "gmm-gpu"` in SieTill.cpp:116-131;
 //                                        per-sequence dense table like NeuralNetwork (NeuralNetwork.cpp:184-199)
 //   gpu_recognize(...)                   batch replacement for the utterance loop of Recognizer::recognize
-//                                        (Recognizer.cpp:46-78): one device pass over the whole Corpus
+//                                        (Recognizer.cpp:46-78): one device pass over the whole Corpus, or -- given
+//                                        several scorer replicas -- one shard per device
 #ifndef __GPU_MIXTURE_SCORER_HPP__
 #define __GPU_MIXTURE_SCORER_HPP__
 
@@ -93,6 +94,55 @@ inline void gpu_recognize(GpuMixtureScorer const& scorer, Lexicon const& lexicon
                                     corpus_size, words.data(), out_off.data());
   sr_lexicon_destroy(net);
   if (rc != SR_OK) {
+    throw std::runtime_error(sr_last_error());
+  }
+  recognized.resize(corpus_size);
+  for (size_t s = 0; s < corpus_size; s++) {
+    recognized[s].assign(words.begin() + out_off[s], words.begin() + out_off[s + 1]);
+  }
+}
+
+// The same over several devices: Recognizer::recognize's `#pragma omp parallel for` over segments (Recognizer.cpp:46-47) at
+// device granularity.  One GpuMixtureScorer replica per entry of `scorers` (each constructed on its device from the same
+// model file); the library deals the segments to them by frames (greedy LPT), runs one host thread per replica and returns
+// the word sequences in corpus order.  No collective: segments are independent.
+inline void gpu_recognize(std::vector<GpuMixtureScorer*> const& scorers, Lexicon const& lexicon, TdpModel const& tdp_model,
+                          double tdp_loop, double tdp_forward, double tdp_skip,
+                          double am_threshold, double word_penalty, Corpus const& corpus, size_t corpus_size,
+                          std::vector<std::vector<WordIdx> >& recognized) {
+  std::vector<uint32_t> word_off(1, 0u);
+  std::vector<uint16_t> automaton;
+  for (WordIdx w = 0; w < lexicon.num_words(); w++) {
+    MarkovAutomaton const& a = lexicon.get_automaton_for_word(w);
+    automaton.insert(automaton.end(), a.states.begin(), a.states.end());
+    word_off.push_back(automaton.size());
+  }
+  const double tdp[3] = {tdp_loop, tdp_forward, tdp_skip};
+  std::vector<sr_model*>   models;
+  std::vector<sr_lexicon*> nets;
+  struct Cleanup {
+    std::vector<sr_lexicon*>& n;
+    ~Cleanup() { for (size_t i = 0; i < n.size(); i++) sr_lexicon_destroy(n[i]); }
+  } cleanup = {nets};
+  for (size_t d = 0; d < scorers.size(); d++) {
+    sr_lexicon* net = NULL;
+    if (sr_lexicon_create(scorers[d]->handle(), lexicon.num_words(), word_off.data(), automaton.data(), lexicon.silence_idx(),
+                          tdp, tdp_model.silence_state, &net) != SR_OK) {
+      throw std::runtime_error(sr_last_error());
+    }
+    models.push_back(scorers[d]->handle());
+    nets.push_back(net);
+  }
+  const size_t dim = corpus.get_features_per_timeframe();
+  std::vector<uint64_t> frame_off(corpus_size + 1, 0u);
+  for (size_t s = 0; s < corpus_size; s++) {
+    frame_off[s + 1] = corpus.get_feature_offsets(s).second / dim;
+  }
+  std::vector<uint32_t> words(frame_off[corpus_size] + 1);
+  std::vector<uint64_t> out_off(corpus_size + 1);
+  sr_search_params p = {am_threshold, word_penalty, SR_GMM_PREFILTER, 0};
+  if (sr_recognize_batch_multi(models.data(), nets.data(), models.size(), &p, *corpus.get_feature_sequence(0).first,
+                               frame_off.data(), corpus_size, words.data(), out_off.data(), NULL) != SR_OK) {
     throw std::runtime_error(sr_last_error());
   }
   recognized.resize(corpus_size);

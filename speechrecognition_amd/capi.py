@@ -23,7 +23,7 @@ SEARCH_GENERAL_KERNEL = 1
 SYMBOLS = [
     "sr_last_error", "sr_device_count", "sr_model_create", "sr_model_load_mixset", "sr_model_destroy", "sr_model_info",
     "sr_corpus_upload", "sr_corpus_upload_async", "sr_corpus_wait", "sr_corpus_destroy", "sr_shard_utterances", "sr_recognize_batch_multi", "sr_score_corpus", "sr_score_frames", "sr_lexicon_create",
-    "sr_lexicon_destroy", "sr_recognize_corpus", "sr_recognize_batch", "sr_align_corpus", "sr_align_corpus_pruned", "sr_path_scores_corpus", "sr_model_create_from_statistics", "sr_mixset_write", "sr_model_set_tying", "sr_model_tying_info", "sr_accumulate_corpus",
+    "sr_lexicon_destroy", "sr_recognize_corpus", "sr_recognize_batch", "sr_align_corpus", "sr_align_corpus_pruned", "sr_path_scores_corpus", "sr_model_create_from_statistics", "sr_mixset_write", "sr_model_set_tying", "sr_model_tying_info", "sr_model_topology", "sr_accumulate_corpus",
     "sr_bigram_create", "sr_bigram_destroy", "sr_recognize_bigram_corpus",
     "sr_probe_fp16_denormals", "sr_probe_fp16_accumulation",
     "sr_profile_enable", "sr_profile_reset", "sr_profile_read",
@@ -87,6 +87,7 @@ def lib():
         L.sr_mixset_write.argtypes = [C.c_char_p, u32, u32, vp, u32, u32, vp, vp, vp, vp, vp, vp]
         L.sr_model_set_tying.argtypes = [vp, u32, u32, vp, vp]
         L.sr_model_tying_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
+        L.sr_model_topology.argtypes = [vp, vp, vp, vp]
         L.sr_accumulate_corpus.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp]
         L.sr_bigram_create.argtypes = [vp, u32, vp, vp, u32, vp, vp, C.POINTER(vp)]
         L.sr_bigram_destroy.argtypes = [vp]
@@ -152,6 +153,13 @@ class Model:
                                                      _ptr(dens_var), _ptr(ma), _ptr(mw), _ptr(va), _ptr(vw), pooling, int(max_approx),
                                                      C.byref(h)))
         return cls(h)
+
+    def topology(self):
+        """-> (dens_off u32[S+1], dens_mean u32[C], dens_var u32[C]): what mixset_write / from_statistics take."""
+        off = np.zeros(self.n_states + 1, np.uint32)
+        dm, dv = np.zeros(self.n_densities, np.uint32), np.zeros(self.n_densities, np.uint32)
+        _check(lib().sr_model_topology(self.h, _ptr(off), _ptr(dm), _ptr(dv)))
+        return off, dm, dv
 
     def close(self):
         if self.h:

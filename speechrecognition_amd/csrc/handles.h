@@ -69,7 +69,7 @@ struct sr_model {
   DevBuf<double> means, inv_vars, norm, logw;
   // EM tying (accumulator rows)
   DevBuf<uint32_t> dens_mean, dens_var;
-  std::vector<uint32_t> h_dens_off;
+  std::vector<uint32_t> h_dens_off, h_dens_mean, h_dens_var;
   // host copies of the finalised tables: the kernel-specific packings are built on first use of that kernel
   std::vector<double> h_means, h_inv_vars, h_norm, h_logw;
   bool mfma_packed = false, pf_packed = false;

@@ -548,6 +548,7 @@ int sr_model_create(int device, uint32_t dim, uint32_t n_states, const uint32_t*
       std::vector<uint32_t> ident(C);
       std::iota(ident.begin(), ident.end(), 0u);
       m->n_mean = m->n_var = (uint32_t)C;
+      m->h_dens_mean = ident; m->h_dens_var = ident;
       if ((e = m->dens_mean.upload(ident.data(), C)) != hipSuccess || (e = m->dens_var.upload(ident.data(), C)) != hipSuccess)
         rc = fail(SR_EHIP, "tying upload: %s", hipGetErrorString(e));
     }
@@ -1200,6 +1201,18 @@ int sr_model_set_tying(sr_model* m, uint32_t n_mean, uint32_t n_var, const uint3
   HIP_TRY(m->dens_mean.upload(dens_mean, m->n_dens));
   HIP_TRY(m->dens_var.upload(dens_var, m->n_dens));
   m->n_mean = n_mean; m->n_var = n_var;
+  m->h_dens_mean.assign(dens_mean, dens_mean + m->n_dens);
+  m->h_dens_var.assign(dens_var, dens_var + m->n_dens);
+  return SR_OK;
+  });
+}
+
+int sr_model_topology(const sr_model* m, uint32_t* dens_off, uint32_t* dens_mean, uint32_t* dens_var) {
+  return guarded(__func__, [&]() -> int {
+  if (!m) return fail(SR_EINVAL, "null model handle");
+  if (dens_off) std::copy(m->h_dens_off.begin(), m->h_dens_off.end(), dens_off);
+  if (dens_mean) std::copy(m->h_dens_mean.begin(), m->h_dens_mean.end(), dens_mean);
+  if (dens_var) std::copy(m->h_dens_var.begin(), m->h_dens_var.end(), dens_var);
   return SR_OK;
   });
 }
