@@ -73,7 +73,9 @@ SR_API int sr_model_create(int device, uint32_t dim, uint32_t n_states, const ui
 SR_API int sr_model_load_mixset(const char* path, uint32_t dim, int pooling, int max_approx, int device, sr_model** out);
 /* MixtureModel::finalize (Mixtures.cpp:374-461) on in-memory statistics -- the model update of an EM iteration:
  * accumulators as sr_accumulate_corpus returns them (+ the topology: dens_off, accumulator rows per density) ->
- * new device model.  sr_mixset_write stores the same statistics as a MIXSET v2 file exactly like
+ * new device model.  The divisions, variances and per-density tables are computed on the device, in the reference's
+ * operation order; the logarithms (norm_, mean_weights_log_) go through the host's libm so that the tables carry the
+ * reference's bits (the variances come back to the host for that).  sr_mixset_write stores the same statistics as a MIXSET v2 file exactly like
  * MixtureModel::write (Mixtures.cpp:834-878: unreferenced rows dropped and renumbered). */
 SR_API int sr_model_create_from_statistics(int device, uint32_t dim, uint32_t n_states, const uint32_t* dens_off,
                                            uint32_t n_mean, uint32_t n_var, const uint32_t* dens_mean, const uint32_t* dens_var,
@@ -193,6 +195,11 @@ SR_API int sr_model_topology(const sr_model* m, uint32_t* dens_off, uint32_t* de
  * several GPUs every rank accumulates its shard and the four arrays are all-reduced (sum) by the caller. */
 SR_API int sr_accumulate_corpus(sr_model* m, sr_corpus* c, const uint16_t* states, int first_pass, int max_approx,
                                 double* mean_acc, double* mean_w, double* var_acc, double* var_w);
+/* The single-device EM iteration without the PCIe round trip: call sr_accumulate_corpus with all four output arrays NULL -- the
+ * statistics then stay in the corpus handle on the device -- and finalise them here into the next model (MixtureModel::finalize,
+ * Mixtures.cpp:374-461; same topology and tying as `m`).  The tables are built in HBM; only the 2 x n weights and the variances
+ * (for the host-side logarithms, see sr_model_create_from_statistics) cross the bus. */
+SR_API int sr_model_create_from_accumulated(sr_model* m, sr_corpus* c, int pooling, int max_approx, sr_model** out);
 
 /* ---- bigram-LM beam search over a linear lexicon ---------------------------------------------------------------
  * Replaces Teaching::LinearSearch (rwth-asr-0.5/src/Teaching/LinearSearch.cc: initialize :489-495, processFrame

@@ -23,7 +23,7 @@ SEARCH_GENERAL_KERNEL = 1
 SYMBOLS = [
     "sr_last_error", "sr_device_count", "sr_model_create", "sr_model_load_mixset", "sr_model_destroy", "sr_model_info",
     "sr_corpus_upload", "sr_corpus_upload_async", "sr_corpus_wait", "sr_corpus_destroy", "sr_shard_utterances", "sr_recognize_batch_multi", "sr_score_corpus", "sr_score_frames", "sr_lexicon_create",
-    "sr_lexicon_destroy", "sr_recognize_corpus", "sr_recognize_batch", "sr_align_corpus", "sr_align_corpus_pruned", "sr_path_scores_corpus", "sr_model_create_from_statistics", "sr_mixset_write", "sr_model_set_tying", "sr_model_tying_info", "sr_model_topology", "sr_accumulate_corpus",
+    "sr_lexicon_destroy", "sr_recognize_corpus", "sr_recognize_batch", "sr_align_corpus", "sr_align_corpus_pruned", "sr_path_scores_corpus", "sr_model_create_from_statistics", "sr_model_create_from_accumulated", "sr_mixset_write", "sr_model_set_tying", "sr_model_tying_info", "sr_model_topology", "sr_accumulate_corpus",
     "sr_bigram_create", "sr_bigram_destroy", "sr_recognize_bigram_corpus",
     "sr_probe_fp16_denormals", "sr_probe_fp16_accumulation",
     "sr_profile_enable", "sr_profile_reset", "sr_profile_read",
@@ -84,6 +84,7 @@ def lib():
         L.sr_align_corpus_pruned.argtypes = [vp, vp, vp, vp, C.POINTER(dbl * 3), C.c_uint16, dbl, i32, vp, vp]
         L.sr_path_scores_corpus.argtypes = [vp, vp, vp, i32, vp]
         L.sr_model_create_from_statistics.argtypes = [i32, u32, u32, vp, u32, u32, vp, vp, vp, vp, vp, vp, i32, i32, C.POINTER(vp)]
+        L.sr_model_create_from_accumulated.argtypes = [vp, vp, i32, i32, C.POINTER(vp)]
         L.sr_mixset_write.argtypes = [C.c_char_p, u32, u32, vp, u32, u32, vp, vp, vp, vp, vp, vp]
         L.sr_model_set_tying.argtypes = [vp, u32, u32, vp, vp]
         L.sr_model_tying_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32)]
@@ -298,6 +299,17 @@ class Corpus:
             _check(lib().sr_align_corpus_pruned(self.model.h, self.h, _ptr(flat), _ptr(off), C.byref(t3), silence_state,
                                                 float(pruning_threshold), kernel, _ptr(states), _ptr(cost)))
         return states[: self.n_frames], cost[: self.n_utts]
+
+    def accumulate_on_device(self, states, first_pass=False, max_approx=True):
+        """The same, but the statistics stay in this corpus handle on the device (for next_model())."""
+        states = np.ascontiguousarray(states, dtype=np.uint16)
+        _check(lib().sr_accumulate_corpus(self.model.h, self.h, _ptr(states), int(first_pass), int(max_approx), None, None, None, None))
+
+    def next_model(self, pooling=POOL_NONE, max_approx=True):
+        """MixtureModel::finalize of the statistics accumulate_on_device() left on the device -> new Model."""
+        h = C.c_void_p()
+        _check(lib().sr_model_create_from_accumulated(self.model.h, self.h, pooling, int(max_approx), C.byref(h)))
+        return Model(h)
 
     def accumulate(self, states, first_pass=False, max_approx=True):
         """EM statistics of an alignment (MixtureModel::accumulate) -> (mean_acc, mean_w, var_acc, var_w)."""

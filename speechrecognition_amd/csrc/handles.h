@@ -130,6 +130,8 @@ struct sr_corpus {
   DevBuf<uint64_t> pair_off;
   DevBuf<uint32_t> pair_frame, key_mean, key_var, iota, keys_sorted, pairs_sorted, row_begin;
   DevBuf<double> pair_w, acc_mean, acc_var, w_mean, w_var;
+  bool acc_valid = false;           // acc_* hold the statistics of the last sr_accumulate_corpus (for sr_model_create_from_accumulated)
+  uint32_t acc_n_mean = 0, acc_n_var = 0;
   DevBuf<unsigned char> sort_temp;
 };
 
@@ -158,6 +160,14 @@ struct sr_bigram {
 };
 
 namespace srhost {
+// (srgpu_api.cpp) handle without parameter tables / lazily fetched host copies of them
+int model_shell(int device, uint32_t dim, uint32_t n_states, const uint32_t* dens_off, int max_approx, sr_model** out);
+int ensure_host_tables(sr_model* m);
+// (em_finalize.hip) MixtureModel::finalize on the device: statistics (host arrays) -> new model whose tables are built in HBM
+int finalize_on_device(int device, uint32_t dim, uint32_t n_states, const uint32_t* dens_off, uint32_t n_mean, uint32_t n_var,
+                       const uint32_t* dens_mean, const uint32_t* dens_var, const double* mean_acc, const double* mean_w,
+                       const double* var_acc, const double* var_w, int pooling, int max_approx, sr_model** out);
+int finalize_accumulated(sr_model* m, sr_corpus* c, int pooling, int max_approx, sr_model** out);
 // (feeder.cpp) make frames [f0, f1) of the corpus visible to work queued on `stream` afterwards: returns at once for a
 // synchronously uploaded corpus; for sr_corpus_upload_async it waits (host) until the feeder has issued the pieces that
 // cover the range and makes the stream wait for their copy events.  Returns the feeder's error, if any.

@@ -5,7 +5,9 @@
 // calculate_variance :251-275).  The arithmetic below keeps the reference's operation order
 // (acc / weight, then  - mean*mean, 1 / var, left-to-right log sum) so that the tables, and with
 // them the SR_GMM_EXACT scores, are bit-identical to the reference's private means_/vars_inv_/
-// norm_/mean_weights_log_.  One-off work, stays on the host like in the reference.
+// norm_/mean_weights_log_.  Since round 2 the arithmetic runs on the device (em_finalize.hip: srhost::finalize_on_device;
+// the logarithms stay on the host's libm); finalize_mixset below is the host-only version of the same, kept as a
+// cross-check (SRGPU_HOST_FINALIZE=1).
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -14,7 +16,10 @@
 #include <thread>
 #include <vector>
 
+#include <cstdlib>
+
 #include "../../include/srgpu.h"
+#include "handles.h"
 #include "host_util.h"
 
 namespace {
@@ -298,6 +303,23 @@ static const char* write_mixset_file(const char* path, const Mixset& ms) {
 
 using srhost::guarded;
 
+// flat topology + accumulators of a parsed file, for the device-side finalize
+static int mixset_to_model(const Mixset& ms, int pooling, int max_approx, int device, sr_model** out) {
+  std::vector<uint32_t> dens_off(1, 0u), dens_mean, dens_var;
+  for (auto& mix : ms.mixtures) {
+    for (const Density& dn : mix) { dens_mean.push_back(dn.mean); dens_var.push_back(dn.var); }
+    dens_off.push_back((uint32_t)dens_mean.size());
+  }
+  if (dens_mean.empty()) { dens_mean.push_back(0); dens_var.push_back(0); }  // (non-null pointers for an empty model)
+  return srhost::finalize_on_device(device, ms.dim, (uint32_t)ms.mixtures.size(), dens_off.data(), ms.mean_acc.n, ms.var_acc.n,
+                                    dens_mean.data(), dens_var.data(), ms.mean_acc.sum.data(), ms.mean_acc.weight.data(),
+                                    ms.var_acc.sum.data(), ms.var_acc.weight.data(), pooling, max_approx, out);
+}
+static bool host_finalize_requested() {
+  const char* e = getenv("SRGPU_HOST_FINALIZE");
+  return e && atoi(e) != 0;
+}
+
 static int tables_to_model(const srhost::MixsetTables& t, uint32_t dim, int max_approx, int device, sr_model** out) {
   int rc = sr_model_create(device, dim, (uint32_t)t.dens_off.size() - 1, t.dens_off.data(), t.means.data(), t.inv_vars.data(),
                            t.norm.data(), t.logw.data(), max_approx, out);
@@ -316,6 +338,9 @@ extern "C" SR_API int sr_model_create_from_statistics(int device, uint32_t dim, 
   return guarded(__func__, [&]() -> int {
   if (!out) return srhost::set_error(SR_EINVAL, "out is null");
   if (pooling < 0 || pooling > 2) return srhost::set_error(SR_EINVAL, "pooling must be 0 (global), 1 (mixture) or 2 (none)");
+  if (!host_finalize_requested())
+    return srhost::finalize_on_device(device, dim, n_states, dens_off, n_mean, n_var, dens_mean, dens_var, mean_acc, mean_w, var_acc,
+                                      var_w, pooling, max_approx, out);
   Mixset ms;
   if (const char* e = srhost::mixset_from_arrays(dim, n_states, dens_off, n_mean, n_var, dens_mean, dens_var, mean_acc, mean_w, var_acc, var_w, &ms))
     return srhost::set_error(SR_EINVAL, e);
@@ -343,6 +368,12 @@ extern "C" SR_API int sr_model_load_mixset(const char* path, uint32_t dim, int p
   return guarded(__func__, [&]() -> int {
   if (!path || !out) return srhost::set_error(SR_EINVAL, "null argument");
   if (pooling < 0 || pooling > 2) return srhost::set_error(SR_EINVAL, "pooling must be 0 (global), 1 (mixture) or 2 (none)");
+  if (!host_finalize_requested()) {
+    Mixset ms;
+    if (const char* e = srhost::parse_mixset(path, dim, &ms)) return srhost::set_error(SR_EINVAL, e);
+    if (ms.mixtures.empty()) return srhost::set_error(SR_EINVAL, "dim and n_states must be positive");
+    return mixset_to_model(ms, pooling, max_approx, device, out);
+  }
   srhost::MixsetTables t;
   if (const char* e = srhost::load_mixset(path, dim, pooling, &t)) return srhost::set_error(SR_EINVAL, e);
   return tables_to_model(t, dim, max_approx, device, out);

@@ -328,6 +328,10 @@ int prof_end(sr_model* m, hipStream_t s, EventPair* ep) {
 // kernel-specific model packing (first use) and workspaces for scoring launches of up to n_max frames: growing a
 // workspace frees the old one, which must not happen between launches that are still queued
 int reserve_scoring(sr_model* m, int gmm_kernel, uint64_t n_max) {
+  if ((gmm_kernel == SR_GMM_MFMA && !m->mfma_packed) || (gmm_kernel == SR_GMM_PREFILTER && !m->pf_packed)) {
+    int rc = srhost::ensure_host_tables(m);
+    if (rc) return rc;
+  }
   if (gmm_kernel == SR_GMM_MFMA && !m->mfma_packed) {
     int rc = pack_model(m, m->h_dens_off.data(), m->h_means.data(), m->h_inv_vars.data(), m->h_norm.data(), m->h_logw.data());
     if (rc) return rc;
@@ -487,12 +491,15 @@ int sr_device_count(int* count) {
   });
 }
 
-int sr_model_create(int device, uint32_t dim, uint32_t n_states, const uint32_t* dens_off, const double* means,
-                    const double* inv_vars, const double* norm, const double* logw, int max_approx, sr_model** out) {
-  return guarded(__func__, [&]() -> int {
-  if (!out) return fail(SR_EINVAL, "out is null");
+}  // extern "C"
+
+namespace srhost {
+
+// A model handle with everything but the four parameter tables: device checks, streams, events, dens_off, chunk sizes.
+// sr_model_create uploads host tables into it; the device-side finalize (em_finalize.hip) fills them where they are.
+int model_shell(int device, uint32_t dim, uint32_t n_states, const uint32_t* dens_off, int max_approx, sr_model** out) {
   *out = nullptr;
-  if (!dens_off || !means || !inv_vars || !norm || !logw) return fail(SR_EINVAL, "null model table");
+  if (!dens_off) return fail(SR_EINVAL, "null model table");
   if (dim == 0 || n_states == 0) return fail(SR_EINVAL, "dim and n_states must be positive");
   const int ks = gmm_mfma_ksteps_for_dim(dim);
   if (ks == 0) return fail(SR_ELIMIT, "dim %u unsupported (max 63)", dim);
@@ -514,46 +521,19 @@ int sr_model_create(int device, uint32_t dim, uint32_t n_states, const uint32_t*
   m->device = device; m->dim = dim; m->n_states = n_states; m->n_dens = C; m->max_approx = max_approx != 0;
   m->ksteps = ks;
   m->ld = (n_states + 7u) & ~7u;  // 64-byte rows pieces for the kernels that write 8 states per thread
-  int rc = SR_OK;
-  do {
-    hipError_t e;
-    if ((e = hipStreamCreateWithFlags(&m->s_gmm, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&m->s_search, hipStreamNonBlocking)) != hipSuccess) {
-      rc = fail(SR_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
-      break;
-    }
-    for (int i = 0; i < 2 && rc == SR_OK; i++) {
-      if ((e = hipEventCreateWithFlags(&m->ev_scored[i], hipEventDisableTiming)) != hipSuccess ||
-          (e = hipEventCreateWithFlags(&m->ev_consumed[i], hipEventDisableTiming)) != hipSuccess)
-        rc = fail(SR_EHIP, "hipEventCreate: %s", hipGetErrorString(e));
-    }
-    if (rc) break;
-    if ((e = m->dens_off.upload(dens_off, n_states + 1)) != hipSuccess || (e = m->means.upload(means, C * dim)) != hipSuccess ||
-        (e = m->inv_vars.upload(inv_vars, C * dim)) != hipSuccess || (e = m->norm.upload(norm, C)) != hipSuccess ||
-        (e = m->logw.upload(logw, C)) != hipSuccess) {
-      rc = fail(SR_EHIP, "model upload: %s", hipGetErrorString(e));
-      break;
-    }
-    {
-      uint32_t mx = 0;
-      for (uint32_t s = 0; s < n_states; s++) mx = std::max(mx, dens_off[s + 1] - dens_off[s]);
-      m->max_dens = std::max(1u, mx);
-      m->h_dens_off.assign(dens_off, dens_off + n_states + 1);
-      m->h_means.assign(means, means + C * dim);
-      m->h_inv_vars.assign(inv_vars, inv_vars + C * dim);
-      m->h_norm.assign(norm, norm + C);
-      m->h_logw.assign(logw, logw + C);
-    }
-    if (rc == SR_OK) {
-      std::vector<uint32_t> ident(C);
-      std::iota(ident.begin(), ident.end(), 0u);
-      m->n_mean = m->n_var = (uint32_t)C;
-      m->h_dens_mean = ident; m->h_dens_var = ident;
-      if ((e = m->dens_mean.upload(ident.data(), C)) != hipSuccess || (e = m->dens_var.upload(ident.data(), C)) != hipSuccess)
-        rc = fail(SR_EHIP, "tying upload: %s", hipGetErrorString(e));
-    }
-  } while (0);
-  if (rc != SR_OK) return rc;
+  hipError_t e;
+  if ((e = hipStreamCreateWithFlags(&m->s_gmm, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&m->s_search, hipStreamNonBlocking)) != hipSuccess)
+    return fail(SR_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+  for (int i = 0; i < 2; i++)
+    if ((e = hipEventCreateWithFlags(&m->ev_scored[i], hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&m->ev_consumed[i], hipEventDisableTiming)) != hipSuccess)
+      return fail(SR_EHIP, "hipEventCreate: %s", hipGetErrorString(e));
+  if ((e = m->dens_off.upload(dens_off, n_states + 1)) != hipSuccess) return fail(SR_EHIP, "model upload: %s", hipGetErrorString(e));
+  uint32_t mx = 0;
+  for (uint32_t s = 0; s < n_states; s++) mx = std::max(mx, dens_off[s + 1] - dens_off[s]);
+  m->max_dens = std::max(1u, mx);
+  m->h_dens_off.assign(dens_off, dens_off + n_states + 1);
   const char* env = getenv("SRGPU_SCORE_CHUNK_MB");
   // score workspace per chunk: 16 GiB by default (two such buffers only when a corpus needs more than one
   // chunk).  Bigger chunks mean fewer, longer GMM launches -- measured 68 vs 65 TFLOP/s at 4 GiB -- and
@@ -563,6 +543,53 @@ int sr_model_create(int device, uint32_t dim, uint32_t n_states, const uint32_t*
   // the refinement kernel addresses the transposed feature copy of a chunk with 32-bit buffer offsets
   m->chunk_frames = std::min<size_t>(m->chunk_frames, ((size_t)1 << 32) / (4 * (size_t)dim) - 128);
   if (const char* ov = getenv("SRGPU_OVERLAP")) m->overlap = atoi(ov) != 0;
+  *out = own.release();
+  return SR_OK;
+}
+
+// host copies of the parameter tables, for the kernel-specific packings: a model finalised on the device has none until
+// a packing is asked for
+int ensure_host_tables(sr_model* m) {
+  const size_t C = m->n_dens, D = m->dim;
+  if (m->h_norm.size() == C && m->h_means.size() == C * D) return SR_OK;
+  m->h_means.resize(C * D); m->h_inv_vars.resize(C * D); m->h_norm.resize(C); m->h_logw.resize(C);
+  if (C == 0) return SR_OK;
+  HIP_TRY(hipMemcpy(m->h_means.data(), m->means.p, C * D * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(m->h_inv_vars.data(), m->inv_vars.p, C * D * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(m->h_norm.data(), m->norm.p, C * sizeof(double), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(m->h_logw.data(), m->logw.p, C * sizeof(double), hipMemcpyDeviceToHost));
+  return SR_OK;
+}
+
+}  // namespace srhost
+
+extern "C" {
+
+int sr_model_create(int device, uint32_t dim, uint32_t n_states, const uint32_t* dens_off, const double* means,
+                    const double* inv_vars, const double* norm, const double* logw, int max_approx, sr_model** out) {
+  return guarded(__func__, [&]() -> int {
+  if (!out) return fail(SR_EINVAL, "out is null");
+  *out = nullptr;
+  if (!dens_off || !means || !inv_vars || !norm || !logw) return fail(SR_EINVAL, "null model table");
+  sr_model* m = nullptr;
+  int rc = srhost::model_shell(device, dim, n_states, dens_off, max_approx, &m);
+  if (rc != SR_OK) return rc;
+  std::unique_ptr<sr_model, int (*)(sr_model*)> own(m, sr_model_destroy);
+  const uint64_t C = m->n_dens;
+  hipError_t e;
+  if ((e = m->means.upload(means, C * dim)) != hipSuccess || (e = m->inv_vars.upload(inv_vars, C * dim)) != hipSuccess ||
+      (e = m->norm.upload(norm, C)) != hipSuccess || (e = m->logw.upload(logw, C)) != hipSuccess)
+    return fail(SR_EHIP, "model upload: %s", hipGetErrorString(e));
+  m->h_means.assign(means, means + C * dim);
+  m->h_inv_vars.assign(inv_vars, inv_vars + C * dim);
+  m->h_norm.assign(norm, norm + C);
+  m->h_logw.assign(logw, logw + C);
+  std::vector<uint32_t> ident(C);
+  std::iota(ident.begin(), ident.end(), 0u);
+  m->n_mean = m->n_var = (uint32_t)C;
+  m->h_dens_mean = ident; m->h_dens_var = ident;
+  if ((e = m->dens_mean.upload(ident.data(), C)) != hipSuccess || (e = m->dens_var.upload(ident.data(), C)) != hipSuccess)
+    return fail(SR_EHIP, "tying upload: %s", hipGetErrorString(e));
   *out = own.release();
   return SR_OK;
   });
@@ -1232,15 +1259,20 @@ int sr_accumulate_corpus(sr_model* m, sr_corpus* c, const uint16_t* states, int 
   int rc = check_model(m);
   if (rc) return rc;
   if (!c || c->model != m) return fail(SR_EINVAL, "corpus does not belong to this model");
-  if (!mean_acc || !mean_w || !var_acc || !var_w) return fail(SR_EINVAL, "null output");
+  const bool to_host = mean_acc || mean_w || var_acc || var_w;  // all NULL: the statistics stay on the device
+  if (to_host && (!mean_acc || !mean_w || !var_acc || !var_w)) return fail(SR_EINVAL, "null output (pass all four arrays, or none)");
   const uint64_t F = c->n_frames;
   const uint32_t D = m->dim;
-  // empty result = reset_accumulators()
-  std::fill(mean_acc, mean_acc + (size_t)m->n_mean * D, 0.0);
-  std::fill(mean_w, mean_w + m->n_mean, 0.0);
-  std::fill(var_acc, var_acc + (size_t)m->n_var * D, 1e-4);
-  std::fill(var_w, var_w + m->n_var, 0.0);
-  if (F == 0) return SR_OK;
+  c->acc_valid = false;
+  if (F == 0) {  // empty result = reset_accumulators()
+    if (to_host) {
+      std::fill(mean_acc, mean_acc + (size_t)m->n_mean * D, 0.0);
+      std::fill(mean_w, mean_w + m->n_mean, 0.0);
+      std::fill(var_acc, var_acc + (size_t)m->n_var * D, 1e-4);
+      std::fill(var_w, var_w + m->n_var, 0.0);
+    }
+    return to_host ? SR_OK : fail(SR_EINVAL, "empty corpus: nothing to keep on the device");
+  }
   if (!states) return fail(SR_EINVAL, "states is null");
   const bool soft = !first_pass && !max_approx;
   std::vector<uint64_t> pair_off(F);
@@ -1251,7 +1283,7 @@ int sr_accumulate_corpus(sr_model* m, sr_corpus* c, const uint16_t* states, int 
     n_pairs += soft ? (m->h_dens_off[states[f] + 1] - m->h_dens_off[states[f]]) : 1;
   }
   if (n_pairs >= (1ull << 31)) return fail(SR_ELIMIT, "too many (frame, density) pairs");
-  if (n_pairs == 0) return SR_OK;
+  if (n_pairs == 0) return fail(SR_EINVAL, "no (frame, density) pairs to accumulate");
   if ((rc = srhost::corpus_ready(c, 0, F, m->s_gmm))) return rc;
   HIP_TRY(c->out_states.upload(states, F));
   HIP_TRY(c->pair_off.upload(pair_off.data(), F));
@@ -1279,11 +1311,26 @@ int sr_accumulate_corpus(sr_model* m, sr_corpus* c, const uint16_t* states, int 
                                c->acc_var.p, c->w_var.p, m->s_gmm));
   if ((rc = prof_end(m, m->s_gmm, &ep))) return rc;
   HIP_TRY(hipStreamSynchronize(m->s_gmm));
-  HIP_TRY(hipMemcpy(mean_acc, c->acc_mean.p, sizeof(double) * (size_t)m->n_mean * D, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(mean_w, c->w_mean.p, sizeof(double) * m->n_mean, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(var_acc, c->acc_var.p, sizeof(double) * (size_t)m->n_var * D, hipMemcpyDeviceToHost));
-  HIP_TRY(hipMemcpy(var_w, c->w_var.p, sizeof(double) * m->n_var, hipMemcpyDeviceToHost));
+  c->acc_valid = true; c->acc_n_mean = m->n_mean; c->acc_n_var = m->n_var;
+  if (to_host) {
+    HIP_TRY(hipMemcpy(mean_acc, c->acc_mean.p, sizeof(double) * (size_t)m->n_mean * D, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(mean_w, c->w_mean.p, sizeof(double) * m->n_mean, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(var_acc, c->acc_var.p, sizeof(double) * (size_t)m->n_var * D, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(var_w, c->w_var.p, sizeof(double) * m->n_var, hipMemcpyDeviceToHost));
+  }
   return SR_OK;
+  });
+}
+
+int sr_model_create_from_accumulated(sr_model* m, sr_corpus* c, int pooling, int max_approx, sr_model** out) {
+  return guarded(__func__, [&]() -> int {
+  if (!out) return fail(SR_EINVAL, "out is null");
+  *out = nullptr;
+  int rc = check_model(m);
+  if (rc) return rc;
+  if (!c || c->model != m) return fail(SR_EINVAL, "corpus does not belong to this model");
+  if (pooling < 0 || pooling > 2) return fail(SR_EINVAL, "pooling must be 0 (global), 1 (mixture) or 2 (none)");
+  return srhost::finalize_accumulated(m, c, pooling, max_approx, out);
   });
 }
 

@@ -92,8 +92,8 @@ def test_absurd_counts_in_a_model_file_are_errors_not_aborts(built_lib, tmp_path
 
 
 def test_exception_barrier_turns_bad_alloc_into_a_status(built_lib):
-    """Forces a host allocation that cannot succeed through an entry point that needs no GPU: statistics with 2^32-1
-    accumulator rows x 63 dimensions (2 TB of doubles).  The call must come back with SR_ENOMEM / SR_ELIMIT and a
+    """Forces a host allocation that cannot succeed through an entry point that needs no GPU (sr_mixset_write): statistics with
+    2^32-1 accumulator rows x 63 dimensions (2 TB of doubles).  The call must come back with SR_ENOMEM / SR_ELIMIT and a
     message -- in a child process, so that a regression (SIGABRT) fails this test instead of killing pytest."""
     import sys
     code = r"""
@@ -103,14 +103,14 @@ from speechrecognition_amd import capi
 L = capi.lib()
 off = np.zeros(2, np.uint32); one = np.zeros(1, np.uint32); d = np.zeros(64, np.float64)
 out = C.c_void_p()
-rc = L.sr_model_create_from_statistics(0, 63, 1, off.ctypes.data, 0xFFFFFFFF, 1, one.ctypes.data, one.ctypes.data,
-                                       d.ctypes.data, d.ctypes.data, d.ctypes.data, d.ctypes.data, 2, 1, C.byref(out))
+rc = L.sr_mixset_write(b"/tmp/never_written.mix", 63, 1, off.ctypes.data, 0xFFFFFFFF, 1, one.ctypes.data, one.ctypes.data,
+                       d.ctypes.data, d.ctypes.data, d.ctypes.data, d.ctypes.data)
 print(rc, L.sr_last_error().decode())
 sys.exit(0 if rc in (-4, -5) else 3)
 """ % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
-    assert "sr_model_create_from_statistics" in r.stdout
+    assert "sr_mixset_write" in r.stdout
 
 
 def test_build_stamps_follow_content_not_mtime(built_lib):

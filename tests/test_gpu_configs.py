@@ -154,3 +154,26 @@ def test_global_pooling_em_iteration_on_device(tmp_path):
             for kernel in (capi.GMM_EXACT, capi.GMM_PREFILTER):
                 got = m2.score_frames(c.feats[:32], kernel)
                 assert np.array_equal(got.view(np.uint64), z["em_scores_after"].view(np.uint64))
+
+
+@pytest.mark.parametrize("name", ["tied_variances", "mixture_pooling", "global_pooling", "nan_variance_floor", "sietill_lexicon_d25"])
+def test_device_finalize_equals_host_finalize(name, tmp_path, monkeypatch):
+    """MixtureModel::finalize on the device (em_finalize.hip, the default) against the host-only version of the same
+    arithmetic (SRGPU_HOST_FINALIZE=1) and against the reference's golden scores: every pooling mode, tied variance rows
+    (last writer wins), rows nobody finalises, NaN / non-positive variances -- bit for bit."""
+    c = Case(name, tmp_path)
+    with capi.Model.from_mixset(c.mixset_path, c.dim, c.pooling, c.max_approx) as m:
+        dev = m.score_frames(c.feats, capi.GMM_EXACT)
+        topo = m.topology()
+    monkeypatch.setenv("SRGPU_HOST_FINALIZE", "1")
+    with capi.Model.from_mixset(c.mixset_path, c.dim, c.pooling, c.max_approx) as m:
+        host = m.score_frames(c.feats, capi.GMM_EXACT)
+    monkeypatch.delenv("SRGPU_HOST_FINALIZE")
+    assert np.array_equal(dev.view(np.uint64), host.view(np.uint64))
+    if c.max_approx:
+        c.check_scores(dev, exact=True)
+    # the same statistics through sr_model_create_from_statistics (the EM path)
+    acc = (c.spec.mean_acc, c.spec.mean_w, c.spec.var_acc, c.spec.var_w)
+    with capi.Model.from_statistics(c.dim, topo[0], topo[1], topo[2], acc, pooling=c.pooling, max_approx=c.max_approx) as m2:
+        assert np.array_equal(m2.score_frames(c.feats, capi.GMM_EXACT).view(np.uint64), dev.view(np.uint64))
+        assert np.array_equal(m2.score_frames(c.feats, capi.GMM_PREFILTER).view(np.uint64), dev.view(np.uint64))

@@ -438,6 +438,19 @@ def test_em_iteration_matches_reference_model_file(tmp_path, oracle_lib):
         got_scores = m2.score_frames(z["feats"][:64], capi.GMM_EXACT)
         assert np.array_equal(got_scores.view(np.uint64), want.view(np.uint64))
         _assert_scores_close(m2.score_frames(z["feats"][:64], capi.GMM_MFMA), want)
+    # the same iteration with the statistics kept on the device (no PCIe round trip): sr_accumulate_corpus with NULL outputs,
+    # then sr_model_create_from_accumulated
+    with capi.Model.from_mixset(mp, 39) as m:
+        corpus = m.upload(z["feats"], np.array([0, 500], dtype=np.uint64))
+        with pytest.raises(capi.SrError):
+            corpus.next_model()                      # nothing accumulated yet
+        corpus.accumulate_on_device(z["states"])
+        with corpus.next_model() as m3:
+            assert np.array_equal(m3.score_frames(z["feats"][:64], capi.GMM_EXACT).view(np.uint64), want.view(np.uint64))
+            assert np.array_equal(m3.score_frames(z["feats"][:64], capi.GMM_PREFILTER).view(np.uint64), want.view(np.uint64))
+            t3 = m3.topology()
+            assert np.array_equal(t3[0], dens_off) and np.array_equal(t3[1], dens_mean) and np.array_equal(t3[2], dens_var)
+        corpus.close()
 
 
 @pytest.mark.parametrize("seed,S,M,D,scale,var_floor,dup", [

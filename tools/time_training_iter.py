@@ -41,11 +41,17 @@ with capi.Model.from_mixset(mp, 39) as m:
     def fin():
         m2 = capi.Model.from_statistics(39, dens_off, spec.dens_mean, spec.dens_var, acc)
         m2.close()
-    _, t_fin = timed(fin, 1)
+    _, t_fin = timed(fin, 2)
+    _, t_acc_dev = timed(lambda: c.accumulate_on_device(states))
+    def fin_dev():
+        m3 = c.next_model()
+        m3.close()
+    _, t_fin_dev = timed(fin_dev, 2)
     F = len(feats)
     print(f"GPU ({U} utterances, {F} frames, {lex.n_states} states x {M}): align_pruned {t_align*1e3:.1f} ms "
           f"({F/t_align:,.0f} frames/s), accumulate {t_acc*1e3:.1f} ms ({F/t_acc:,.0f} frames/s), "
-          f"finalize+upload {t_fin*1e3:.1f} ms")
+          f"finalize from host statistics {t_fin*1e3:.1f} ms; statistics kept on the device: accumulate {t_acc_dev*1e3:.1f} ms + "
+          f"finalize {t_fin_dev*1e3:.1f} ms -> EM iteration {1e3*(t_align + t_acc_dev + t_fin_dev):.1f} ms")
     c.close()
 # CPU oracle on a sample: lazy scoring inside the aligner (the reference's cost profile), then accumulate
 n = min(U, 16)
