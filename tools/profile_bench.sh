@@ -1,7 +1,7 @@
 #!/bin/bash
 # Profiles `python3 bench.py` on the GPU box: kernel-trace statistics, then PMC counters in separate passes (HBM
 # traffic, clocks, pipe activity), as MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE do not fit one pass;
-# --pmc is never combined with other trace domains).  Raw CSVs land in gpurun_out/profile_<tag>/; summarise with
+# a --pmc pass carries --kernel-trace only, never --sys-trace / --runtime-trace or the hip/hsa/memory-copy domains).  Raw CSVs land in gpurun_out/profile_<tag>/; summarise with
 # tools/summarize_profile.py and copy the summary into profiles/.
 # usage: gpurun -- 'tools/profile_bench.sh TAG [bench args...]'
 set -e -o pipefail

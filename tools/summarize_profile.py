@@ -18,7 +18,8 @@ out = {"source": "tools/profile_bench.sh: rocprofv3 --kernel-trace --stats (3 ti
        "kernels": {}}
 try:
     out["bench_line_under_profiler"] = json.loads(open(os.path.join(root, "bench_under_profiler.json")).read())
-    out["workload_frames_per_launch"] = out["bench_line_under_profiler"]["config"]["frames_per_gpu_rank0"]
+    cfg = out["bench_line_under_profiler"]["config"]
+    out["workload_frames_per_launch"] = cfg.get("frames_rank0", cfg.get("frames_per_gpu_rank0"))
 except (OSError, ValueError, KeyError):
     pass
 for r in csv.DictReader(open(os.path.join(root, "stats", "s_kernel_stats.csv"))):
