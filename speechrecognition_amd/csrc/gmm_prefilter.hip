@@ -133,15 +133,17 @@ __global__ __launch_bounds__(kPWaves * 64, (NB <= 2 ? 3 : 2)) void gmm_prefilter
     __syncthreads();
   }
 
-  auto issue_stage = [&](uint32_t grp, int buf) {
+  // groups are fetched in order: a running per-lane source pointer (one 64-bit add per piece instead of two)
+  const unsigned char* dma_src = a.apack + (uint64_t)g0 * kStageBytes + (uint64_t)wave * 1024 + lane * 16;
+  auto issue_stage = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < kDmaPerWave; i++) {
       const int chunk = i * kPWaves + wave;
-      const unsigned char* src = a.apack + (uint64_t)grp * kStageBytes + (uint64_t)chunk * 1024 + lane * 16;
       unsigned char* dst = lds + buf * kStageBytes + chunk * 1024;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dma_src + i * (kPWaves * 1024)),
                                        (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
+    dma_src += kStageBytes;
   };
   auto frag = [&](int buf, int j, int ks) -> f16x8 {
     return __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(lds + buf * kStageBytes + j * kBlockBytes + ks * 1024 + lane * 16));
@@ -149,13 +151,23 @@ __global__ __launch_bounds__(kPWaves * 64, (NB <= 2 ? 3 : 2)) void gmm_prefilter
 
   // one stage per group; A fragments are read one k-step ahead, across the stage boundary too
   const uint32_t n_stages = g1 - g0;
-  if (n_stages > 0) issue_stage(g0, 0);
-  if (n_stages > 1) issue_stage(g0 + 1, 1);
+  if (n_stages > 0) issue_stage(0);
+  if (n_stages > 1) issue_stage(1);
   if (n_stages > 1) __builtin_amdgcn_s_waitcnt(0x0F70 | kDmaPerWave);  // vmcnt(kDmaPerWave): stage 0 has landed
   else __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
   f16x8 a_c, a_n;
   if (n_stages > 0) a_c = frag(0, 0, 0);
+  // where the lane's mask words go, relative to the group's first entry (4 n_frames < 2^32: the launcher checks)
+  uint32_t* m_ptr = a.mask + (uint64_t)g0 * a.n_frames * 4u;
+  uint32_t m_off[NB];
+  bool m_ok[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; nb++) {
+    const uint64_t f = frame0 + (uint64_t)nb * 16 + c;
+    m_ok[nb] = f < a.n_frames;
+    m_off[nb] = (uint32_t)f * 4u + (uint32_t)g;
+  }
   for (uint32_t s = 0; s < n_stages; s++) {
     const uint32_t grp = g0 + s;
     const int buf = s & 1;
@@ -171,7 +183,7 @@ __global__ __launch_bounds__(kPWaves * 64, (NB <= 2 ? 3 : 2)) void gmm_prefilter
           if (s + 1 < n_stages) {  // workgroup-uniform
             __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): stage s+1 landed, my reads of stage s returned
             __syncthreads();
-            if (s + 2 < n_stages) issue_stage(grp + 2, buf);
+            if (s + 2 < n_stages) issue_stage(buf);
             a_n = frag(buf ^ 1, 0, 0);
           }
         } else {
@@ -189,6 +201,8 @@ __global__ __launch_bounds__(kPWaves * 64, (NB <= 2 ? 3 : 2)) void gmm_prefilter
     }
     // ---- candidate mask of state slot g of this group, for the lane's frame(s) (scaled units) ---------------------
     const float2 nk = reinterpret_cast<const float2*>(a.grp_anorm)[4u * grp + g];  // sA |a|, sA |konst| (rounded up)
+    // 2 eps = lim1 |b| + lim0 (the bound of the file header, the frame's part factored out: 2 instructions per frame block)
+    const float lim1 = 2.0f * (kKappa16 * nk.x + kAbs16), lim0 = 2.0f * (kKonst16 * nk.y + kAbs16 * nk.x);
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
       // v_min3_f32 directly: the hardware minimum already drops (quiet) NaNs; fminf() would canonicalise every operand
@@ -203,7 +217,7 @@ __global__ __launch_bounds__(kPWaves * 64, (NB <= 2 ? 3 : 2)) void gmm_prefilter
               "v"(ap[nb][j + 1][1]), "v"(ap[nb][j + 1][2]), "v"(ap[nb][j + 1][3]));
       if (a.chunks >= 2) { const float o = __shfl_xor(amin, 16); asm("v_min_f32 %0, %0, %1" : "+v"(amin) : "v"(o)); }  // the other chunk(s) of the state
       if (a.chunks >= 4) { const float o = __shfl_xor(amin, 32); asm("v_min_f32 %0, %0, %1" : "+v"(amin) : "v"(o)); }
-      const float limit = amin + 2.0f * (kKappa16 * nk.x * bnorm[nb] + kKonst16 * nk.y + kAbs16 * (bnorm[nb] + nk.x));
+      const float limit = amin + __builtin_fmaf(lim1, bnorm[nb], lim0);
       uint32_t mask = 0;
 #pragma unroll
       for (int j = kGroupBlocks - 1; j >= 1; j -= 2)  // densities in descending order, two blocks per asm statement
@@ -219,9 +233,9 @@ __global__ __launch_bounds__(kPWaves * 64, (NB <= 2 ? 3 : 2)) void gmm_prefilter
             : "v"(limit), "v"(ap[nb][j][3]), "v"(ap[nb][j][2]), "v"(ap[nb][j][1]), "v"(ap[nb][j][0]), "v"(ap[nb][j - 1][3]),
               "v"(ap[nb][j - 1][2]), "v"(ap[nb][j - 1][1]), "v"(ap[nb][j - 1][0])
             : "vcc");
-      const uint64_t f = frame0 + (uint64_t)nb * 16 + c;
-      if (f < a.n_frames) a.mask[((uint64_t)grp * a.n_frames + f) * 4u + g] = mask;
+      if (m_ok[nb]) m_ptr[m_off[nb]] = mask;
     }
+    m_ptr += a.n_frames * 4u;  // the next group's entries (wave-uniform pointer, 32-bit lane offsets)
   }
 }
 
@@ -354,6 +368,7 @@ hipError_t probe_fp16_accumulation(hipStream_t stream, bool* ok, double* worst_r
 
 hipError_t launch_gmm_prefilter(const GmmPrefilterArgs& a, int ks32, hipStream_t stream) {
   const dim3 grid(a.nx * a.ny), block(kPWaves * 64);
+  if (a.n_frames >= (1ull << 30)) return hipErrorInvalidValue;  // (32-bit mask offsets inside a group)
   switch (ks32) {
     case 1: hipLaunchKernelGGL((gmm_prefilter16_kernel<1, SR_P16_NB>), grid, block, 0, stream, a); break;
     case 2: hipLaunchKernelGGL((gmm_prefilter16_kernel<2, SR_P16_NB>), grid, block, 0, stream, a); break;
