@@ -116,6 +116,8 @@ struct sr_corpus {
   std::vector<uint64_t> frame_off;  // host copy
   DevBuf<float> feats;
   DevBuf<uint64_t> d_frame_off;
+  DevBuf<uint32_t> utt_order;       // per launch range (chunk), its utterances longest first; built for order_chunk_frames
+  size_t order_chunk_frames = 0;    // 0 = not built
   // search outputs (device)
   DevBuf<double> tb_score;
   DevBuf<uint16_t> tb_word, tb_bkp;

@@ -124,6 +124,8 @@ struct DecodeArgs {
   const uint64_t* frame_off;    // [n_utts+1] global frame offsets of the corpus
   uint64_t frame_base;          // scores row 0 is global frame `frame_base`
   uint32_t utt_first, n_utts;   // utterances handled by this launch
+  const uint32_t* utt_order;    // [n_utts_total] workgroup utt_first + b decodes utterance utt_order[utt_first + b]: the launch's range,
+                                // longest first (the tail of a launch is then its shortest utterances); null = identity
   double am_threshold, word_penalty;
   // traceback arrays, entry frame_off[u] + u + t  (t = 0..T_u)
   double* tb_score;
@@ -145,6 +147,7 @@ struct AlignArgs {
   const uint64_t* frame_off;    // [n_utts+1]
   uint64_t frame_base;
   uint32_t utt_first, n_utts;
+  const uint32_t* utt_order;    // as in DecodeArgs
   const uint16_t* automata;     // concatenated reference automata
   const uint64_t* aut_off;      // [n_utts_total+1]
   double tdp_loop, tdp_forward, tdp_skip;
@@ -167,6 +170,7 @@ struct BigramArgs {
   const uint64_t* frame_off;    // [n_utts_total+1]
   uint64_t frame_base;
   uint32_t utt_first, n_utts;
+  const uint32_t* utt_order;    // as in DecodeArgs
   uint32_t n_words, silence, n_positions;  // W; silence word; sum of state counts over the 2W slots (words + silence copies)
   const uint32_t* slot_off;     // [2W+1] first dense position of every slot
   const uint32_t* slot_mix;     // [2W] offset of the slot's acoustic word in `mixtures`

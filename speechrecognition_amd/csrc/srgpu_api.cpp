@@ -440,6 +440,22 @@ std::vector<Chunk> make_chunks(const sr_corpus* c, size_t chunk_frames) {
   return out;
 }
 
+// One workgroup searches / aligns one utterance, and a launch has only a few workgroups per CU (configs[2]: 1000 utterances of
+// 200..400 frames on 256 CUs): handed out in corpus order, the last CU finishes ~19 % after the average one.  Every launch range
+// is therefore walked longest utterance first (ties in corpus order); results do not depend on the order.
+int ensure_utt_order(sr_model* m, sr_corpus* c, const std::vector<Chunk>& chunks) {
+  if (c->order_chunk_frames == m->chunk_frames && c->utt_order.p) return SR_OK;
+  std::vector<uint32_t> order(c->n_utts);
+  for (uint32_t u = 0; u < c->n_utts; u++) order[u] = u;
+  for (const Chunk& ch : chunks)
+    std::stable_sort(order.begin() + ch.u0, order.begin() + ch.u1, [&](uint32_t a, uint32_t b) {
+      return c->frame_off[a + 1] - c->frame_off[a] > c->frame_off[b + 1] - c->frame_off[b];
+    });
+  HIP_TRY(c->utt_order.upload(order.data(), order.size()));
+  c->order_chunk_frames = m->chunk_frames;
+  return SR_OK;
+}
+
 // Scores frames [f0, f1) of the corpus into `table` (row 0 = frame f0).  While the feeder is still copying
 // (sr_corpus_upload_async) the range is scored in three launches -- the first sixth, up to the half, the rest -- each
 // waiting on the device only for its own pieces: scoring starts ~1 ms into the transfer and the rest of it hides behind
@@ -844,6 +860,7 @@ int sr_recognize_corpus(sr_model* m, sr_corpus* c, sr_lexicon* l, const sr_searc
   HIP_TRY(hipMemsetAsync(c->out_flags.p, 0, sizeof(uint32_t) * std::max(1u, U), m->s_gmm));
   const std::vector<Chunk> chunks = make_chunks(c, m->chunk_frames);
   if ((rc = ensure_score_ws(m, chunks))) return rc;
+  if ((rc = ensure_utt_order(m, c, chunks))) return rc;
 
   DecodeArgs da{};
   da.net.n_slots = l->n_slots; da.net.n_words = l->n_words;
@@ -852,7 +869,7 @@ int sr_recognize_corpus(sr_model* m, sr_corpus* c, sr_lexicon* l, const sr_searc
   da.net.tdp_loop = l->tdp[0]; da.net.tdp_forward = l->tdp[1]; da.net.tdp_skip = l->tdp[2];
   da.fast.n_slots = l->f_n; da.fast.state = l->f_state.p; da.fast.pred = l->f_pred.p; da.fast.orig = l->f_orig.p;
   da.fast.chunk_type = l->f_type.p; da.fast.word = l->f_word.p; da.fast.init_slot = l->f_init; da.fast.init_is_end = l->f_init_end;
-  da.ld = m->ld; da.frame_off = c->d_frame_off.p;
+  da.ld = m->ld; da.frame_off = c->d_frame_off.p; da.utt_order = c->utt_order.p;
   da.am_threshold = p->am_threshold; da.word_penalty = p->word_penalty;
   if (p->flags & ~SR_SEARCH_GENERAL_KERNEL) return fail(SR_EINVAL, "unknown sr_search_params.flags 0x%x", (unsigned)p->flags);
   da.force_general = (p->flags & SR_SEARCH_GENERAL_KERNEL) ? 1u : 0u;
@@ -995,7 +1012,8 @@ int sr_recognize_bigram_corpus(sr_model* m, sr_corpus* c, sr_bigram* b, const sr
   HIP_TRY(b->out_flags.ensure(U));
 
   BigramArgs ba{};
-  ba.ld = m->ld; ba.frame_off = c->d_frame_off.p;
+  if ((rc = ensure_utt_order(m, c, chunks))) return rc;
+  ba.ld = m->ld; ba.frame_off = c->d_frame_off.p; ba.utt_order = c->utt_order.p;
   ba.n_words = W; ba.silence = b->silence; ba.n_positions = b->n_positions;
   ba.slot_off = b->slot_off.p; ba.slot_mix = b->slot_mix.p; ba.mixtures = b->mixtures.p; ba.lmT = b->lmT.p; ba.lm_rowmin = b->lm_rowmin.p; ba.lm_rowmax = b->lm_rowmax.p;
   memcpy(ba.tdp, b->tdp, sizeof(ba.tdp));
@@ -1120,7 +1138,8 @@ static int align_common(sr_model* m, sr_corpus* c, const uint16_t* automata, con
     HIP_TRY(c->al_blk_list.upload(blk_list.data(), blk_list.size()));
   }
   AlignArgs aa{};
-  aa.ld = m->ld; aa.frame_off = c->d_frame_off.p; aa.automata = c->automata.p; aa.aut_off = c->aut_off.p;
+  if ((rc = ensure_utt_order(m, c, chunks))) return rc;
+  aa.ld = m->ld; aa.frame_off = c->d_frame_off.p; aa.utt_order = c->utt_order.p; aa.automata = c->automata.p; aa.aut_off = c->aut_off.p;
   aa.tdp_loop = tdp[0]; aa.tdp_forward = tdp[1]; aa.tdp_skip = tdp[2]; aa.silence_state = silence_state;
   aa.pruning_threshold = thr; aa.backptr = c->backptr.p; aa.bp_off = c->bp_off.p; aa.max_positions = max_n;
   aa.out_states = c->out_states.p; aa.out_cost = c->out_cost.p;

@@ -31,7 +31,7 @@ __device__ inline double shfl_xor_f64a(double v, int m) {
 // LDS layout: cost[2][N] f64, ref[N] u16
 __global__ __launch_bounds__(kAlignThreads) void align_full_kernel(AlignArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t u = a.utt_first + blockIdx.x, tid = threadIdx.x;
+  const uint32_t u = a.utt_order ? a.utt_order[a.utt_first + blockIdx.x] : a.utt_first + blockIdx.x, tid = threadIdx.x;
   const uint64_t f0 = a.frame_off[u];
   const int T = (int)(a.frame_off[u + 1] - f0);
   const int N = (int)(a.aut_off[u + 1] - a.aut_off[u]);
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kAlignThreads) void align_full_kernel(AlignArgs a) 
 // LDS layout: cost[2][N] f64, ref[N] u16, alive[2][N] u8, red[4] f64
 __global__ __launch_bounds__(kAlignThreads) void align_pruned_kernel(AlignArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t u = a.utt_first + blockIdx.x, tid = threadIdx.x;
+  const uint32_t u = a.utt_order ? a.utt_order[a.utt_first + blockIdx.x] : a.utt_first + blockIdx.x, tid = threadIdx.x;
   const uint32_t wave = tid >> 6, lane = tid & 63;
   const uint64_t f0 = a.frame_off[u];
   const int T = (int)(a.frame_off[u + 1] - f0);

@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
   L[1] = L[0] + W2;
   uint8_t* active = reinterpret_cast<uint8_t*>(L[1] + W2);    // [2W]
 
-  const uint32_t u = a.utt_first + blockIdx.x, tid = threadIdx.x;
+  const uint32_t u = a.utt_order ? a.utt_order[a.utt_first + blockIdx.x] : a.utt_first + blockIdx.x, tid = threadIdx.x;
   const uint64_t f0 = a.frame_off[u], T = a.frame_off[u + 1] - f0;
   const double* dense = a.scores + (f0 - a.frame_base) * a.ld;
   // per-utterance global workspaces

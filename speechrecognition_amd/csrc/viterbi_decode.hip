@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeArgs a) {
   uint32_t* bail = e_first + 8;                                    // [1] fast variant: an entry slot needs the replay
   uint16_t* bk = reinterpret_cast<uint16_t*>(e_first + 12);         // [PP] back pointers (start frame of the word)
 
-  const uint32_t u = a.utt_first + blockIdx.x;
+  const uint32_t u = a.utt_order ? a.utt_order[a.utt_first + blockIdx.x] : a.utt_first + blockIdx.x;
   if (REPLAY && !a.force_general && !(a.out_flags[u] & 2u)) return;  // wave-uniform: nothing to redo for this utterance
   const uint64_t f0 = a.frame_off[u];
   const uint32_t T = (uint32_t)(a.frame_off[u + 1] - f0);

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
   uint16_t* bk = reinterpret_cast<uint16_t*>(e_first + 12);      // [PP] back pointers
 
   const FastNet& net = a.fast;
-  const uint32_t u = a.utt_first + blockIdx.x;
+  const uint32_t u = a.utt_order ? a.utt_order[a.utt_first + blockIdx.x] : a.utt_first + blockIdx.x;
   const uint64_t f0 = a.frame_off[u];
   const uint32_t T = (uint32_t)(a.frame_off[u + 1] - f0);
   const double* row0 = a.scores + (f0 - a.frame_base) * a.ld;
