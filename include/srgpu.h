@@ -114,7 +114,8 @@ SR_API int sr_score_frames(sr_model* m, const float* feats, uint64_t n_frames, i
  * MarkovAutomaton.hpp:22-28).  tdp = {loop, forward, skip} (TdpModel.cpp:5-7); silence_state as
  * TdpModel::silence_state.  The initial hypothesis sits at position 0 of word 0 like the
  * reference's (Recognizer.cpp:120), which is a word end when word 0 (normally silence) has one
- * position.  Limits: <= 65535 words, <= 8192 positions in total, some word with >= 2 positions. */
+ * position.  Limits: <= 65535 words, <= 65534 positions in total (beyond 8192 type-padded positions the search keeps its
+ * hypotheses in device memory instead of LDS: same results, slower), some word with >= 2 positions. */
 SR_API int sr_lexicon_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, const uint16_t* automaton,
                       uint32_t silence_idx, const double tdp[3], uint16_t silence_state, sr_lexicon** out);
 SR_API int sr_lexicon_destroy(sr_lexicon* l);

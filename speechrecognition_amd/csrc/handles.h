@@ -122,6 +122,7 @@ struct sr_corpus {
   DevBuf<double> tb_score;
   DevBuf<uint16_t> tb_word, tb_bkp;
   DevBuf<uint32_t> out_words, out_count, out_flags;
+  DevBuf<unsigned char> big_ws;     // decode_big_kernel: hypothesis arrays of the utterances in flight
   // aligner workspace
   DevBuf<uint16_t> automata, out_states;
   DevBuf<uint64_t> aut_off, bp_off, al_blk_frame0;
@@ -145,6 +146,7 @@ struct sr_lexicon {
   // type-sorted copy for the fast kernel
   DevBuf<uint32_t> f_state, f_pred, f_orig, f_type, f_word;
   uint32_t f_n = 0, f_init = 0, f_init_end = 0;
+  bool big = false;                 // more slots than the LDS kernels hold: decode_big_kernel, no type-sorted copy
 };
 
 struct sr_bigram {

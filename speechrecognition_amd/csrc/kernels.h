@@ -138,7 +138,11 @@ struct DecodeArgs {
 };
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream);       // fast variant, then the replay variant for flagged utterances
 hipError_t launch_decode_fast(const DecodeArgs& a, hipStream_t stream);
-uint32_t decode_max_slots();
+uint32_t decode_max_slots();          // what the LDS-resident kernels hold
+// lexicons beyond that: hypothesis arrays in a global workspace of n_utts * decode_big_workspace(P) bytes
+uint32_t decode_big_max_slots();
+size_t decode_big_workspace(uint32_t n_slots);
+hipError_t launch_decode_big(const DecodeArgs& a, unsigned char* ws, hipStream_t stream);
 
 // ---- forced aligners (viterbi_align.hip) ----------------------------------------------------------
 struct AlignArgs {

@@ -758,7 +758,7 @@ int sr_lexicon_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, c
   // next word's position 0 when every word has a single position (Recognizer.cpp:139); not reproduced
   if (max_pos < 2) return fail(SR_ELIMIT, "lexicon needs at least one word with two or more positions");
   const uint32_t P = word_off[n_words];
-  if (P > decode_max_slots()) return fail(SR_ELIMIT, "%u trellis positions exceed the decoder's limit of %u", P, decode_max_slots());
+  if (P > decode_big_max_slots()) return fail(SR_ELIMIT, "%u trellis positions exceed the decoder's limit of %u", P, decode_big_max_slots());
   std::vector<uint32_t> info(P), sword(P), wend(n_words);
   for (uint32_t w = 0; w < n_words; w++) {
     const uint32_t b = word_off[w], n = word_off[w + 1] - b;
@@ -802,8 +802,10 @@ int sr_lexicon_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, c
     while (f_orig.size() % 64) f_orig.push_back(0xFFFFFFFFu);
     f_type.resize(f_orig.size() / 64, k);
   }
-  const uint32_t Pn = (uint32_t)f_orig.size();
-  if (Pn > decode_max_slots()) return fail(SR_ELIMIT, "%u type-padded trellis positions exceed the decoder's limit of %u", Pn, decode_max_slots());
+  uint32_t Pn = (uint32_t)f_orig.size();
+  // beyond what the LDS holds (type padding included) the search runs from a global workspace (decode_big_kernel): no fast net
+  const bool big = Pn > decode_max_slots();
+  if (big) { Pn = 0; f_orig.clear(); f_type.clear(); }
   f_state.assign(Pn, 0); f_pred.assign(Pn, 0); f_word.assign(Pn, 0);
   for (uint32_t q = 0; q < Pn; q++) {
     const uint32_t p = f_orig[q];
@@ -816,7 +818,7 @@ int sr_lexicon_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, c
   }
   sr_lexicon* l = new sr_lexicon();
   std::unique_ptr<sr_lexicon, int (*)(sr_lexicon*)> own(l, sr_lexicon_destroy);
-  l->f_n = Pn; l->f_init = new_id[0]; l->f_init_end = (info[0] >> 18) & 1u;
+  l->f_n = Pn; l->f_init = new_id[0]; l->f_init_end = (info[0] >> 18) & 1u; l->big = big;
   l->model = m; l->n_words = n_words; l->n_slots = P; l->silence_idx = silence_idx; l->silence_state = silence_state;
   l->tdp[0] = tdp[0]; l->tdp[1] = tdp[1]; l->tdp[2] = tdp[2];
   hipError_t e;
@@ -862,6 +864,11 @@ int sr_recognize_corpus(sr_model* m, sr_corpus* c, sr_lexicon* l, const sr_searc
   if ((rc = ensure_score_ws(m, chunks))) return rc;
   if ((rc = ensure_utt_order(m, c, chunks))) return rc;
 
+  if (l->big) {  // hypothesis arrays of the utterances in flight
+    uint32_t most = 0;
+    for (const Chunk& ch : chunks) most = std::max(most, ch.u1 - ch.u0);
+    HIP_TRY(c->big_ws.ensure((size_t)most * decode_big_workspace(l->n_slots)));
+  }
   DecodeArgs da{};
   da.net.n_slots = l->n_slots; da.net.n_words = l->n_words;
   da.net.slot_info = l->slot_info.p; da.net.slot_word = l->slot_word.p; da.net.word_end_slot = l->word_end_slot.p;
@@ -888,7 +895,7 @@ int sr_recognize_corpus(sr_model* m, sr_corpus* c, sr_lexicon* l, const sr_searc
     da.scores = m->scores[buf].p; da.frame_base = ch.f0; da.utt_first = ch.u0; da.n_utts = ch.u1 - ch.u0;
     EventPair ep{};
     if ((rc = prof_begin(m, s_search, 1, &ep))) return rc;
-    HIP_TRY(launch_decode(da, s_search));
+    HIP_TRY(l->big ? launch_decode_big(da, c->big_ws.p, s_search) : launch_decode(da, s_search));
     if ((rc = prof_end(m, s_search, &ep))) return rc;
     HIP_TRY(hipEventRecord(m->ev_consumed[buf], s_search));
     if (m->profiling) m->prof.search_bytes += (8.0 * m->n_states + 4.0 * l->n_slots) * (double)(ch.f1 - ch.f0);

@@ -384,6 +384,164 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeArgs a) {
 #endif
 }
 
+// ---- the same search for lexicons whose hypothesis arrays do not fit the LDS (more than 8192 slots) -----------------------
+// Scores and back pointers of the two frames in flight live in a per-workgroup global workspace (20 bytes per slot: L2
+// resident), emission costs are gathered where they are used, and a thread walks its slots in a loop instead of keeping them in
+// registers.  Phases, merge order and the exactness argument are decode_kernel's (REPLAY = true: the sequential boundary
+// replay is inline, per lane); slot ids stay 16 bit in the traceback, so P <= 65534.  A capacity path: measured 12.3 ms for
+// 256 utterances at 9001 slots against 5.3 ms at 8000 slots in the type-sorted LDS kernel (2 x per slot).
+template <int NT>
+__global__ __launch_bounds__(NT) void decode_big_kernel(DecodeArgs a, unsigned char* ws_all, size_t ws_stride) {
+  constexpr uint32_t kWavesPerWg = NT / 64;
+  __shared__ double red_best[kWavesPerWg], red_we[kWavesPerWg];
+  __shared__ uint32_t red_idx[kWavesPerWg], e_first[8];
+  const uint32_t P = a.net.n_slots;
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const uint32_t u = a.utt_order ? a.utt_order[a.utt_first + blockIdx.x] : a.utt_first + blockIdx.x;
+  const uint64_t f0 = a.frame_off[u];
+  const uint32_t T = (uint32_t)(a.frame_off[u + 1] - f0);
+  const double* row0 = a.scores + (f0 - a.frame_base) * a.ld;
+  const uint64_t tb0 = f0 + u;
+  const double tl = a.net.tdp_loop, tf = a.net.tdp_forward, ts = a.net.tdp_skip;
+  const double wp_word = a.word_penalty, thr = a.am_threshold;
+  unsigned char* ws = ws_all + (size_t)blockIdx.x * ws_stride;
+  double* scb[2] = {reinterpret_cast<double*>(ws), reinterpret_cast<double*>(ws) + P};
+  uint16_t* bkb[2] = {reinterpret_cast<uint16_t*>(ws + (size_t)P * 16), reinterpret_cast<uint16_t*>(ws + (size_t)P * 16) + P};
+
+  for (uint32_t p = tid; p < P; p += NT) { scb[0][p] = kInf; bkb[0][p] = 0; }
+  if (tid < 8) e_first[tid] = 0xFFFFFFFFu;
+  __syncthreads();
+  const bool init_is_end = a.net.slot_info[0] & kSlotEnd;
+  double m_we = init_is_end ? 0.0 : kInf;
+  if (tid == 0) {
+    scb[0][0] = 0.0;  // initial hypothesis: word 0, position 0, score 0 (Recognizer.cpp:120)
+    a.tb_score[tb0] = 0.0; a.tb_word[tb0] = 0; a.tb_bkp[tb0] = 0;
+  }
+  if (tid < 4 && init_is_end) e_first[4 + tid] = 0;
+  __syncthreads();
+  uint32_t slow_taken = 0;
+
+  for (uint32_t t = 1; t <= T; t++) {
+    const uint32_t* ef_cur = e_first + 4 * (t & 1);
+    uint32_t* ef_nxt = e_first + 4 * ((t + 1) & 1);
+    const uint32_t bkp_new = (t - 1) & 0xFFFFu;
+    const double* row = row0 + (uint64_t)(t - 1) * a.ld;
+    const double* sc = scb[(t - 1) & 1];
+    const uint16_t* bk = bkb[(t - 1) & 1];
+    double* scn = scb[t & 1];
+    uint16_t* bkn = bkb[t & 1];
+    // ---- A: the new hypotheses, unpruned, into the other buffer ---------------------------------------------------
+    double my_best = kInf, my_we = kInf;
+    uint32_t my_we_idx = 0xFFFFFFFFu;
+    for (uint32_t p = tid; p < P; p += NT) {
+      const uint32_t inf = a.net.slot_info[p];
+      const double am = row[inf & 0xFFFFu];
+      const bool pos0 = inf & kSlotPos0, pos1 = inf & kSlotPos1, entry = pos0 || pos1;
+      const bool sil_state = inf & kSlotSilState;
+      const double t_loop = sil_state ? tf : tl, t_skip = sil_state ? tf : ts;
+      const uint32_t p1 = p - (pos0 ? 0u : 1u), p2 = p - (entry ? 0u : 2u);
+      const double c_skip = entry ? kInf : sc[p2] + t_skip;
+      const double c_fwd = pos0 ? kInf : sc[p1] + tf;
+      const double c_loop = (inf & kSlotEnd) ? kInf : sc[p] + t_loop;  // word ends do not expand in-word (:131)
+      const double am_b = pos1 ? row[a.net.slot_info[p1] & 0xFFFFu] : am;  // emission of the word's position 0 (:136,148-151)
+      const double wp = (inf & kSlotSilWord) ? 0.0 : wp_word;
+      const bool b_skip = pos1 && !(inf & kSlotFirstSil);
+      const double t_b = b_skip ? ts : tf;
+      const uint32_t cls = ((inf & kSlotSilWord) ? 0u : 2u) + (b_skip ? 1u : 0u);
+      Merge mg;
+      if (entry && (am_b < 0.0 || am < 0.0)) {  // the collapsed boundary candidate is only exact while the pre-AM early-out is inert
+        mg = replay_boundary(a.net.word_end_slot, a.net.n_words, sc, bk, p, pos1, !(inf & kSlotEnd), true, wp, t_b, am_b, am, tf, t_loop, bkp_new);
+        slow_taken = 1;
+      } else {
+        const double c_b = entry ? (m_we + wp) + t_b : kInf;  // cur_hyp->score + word_penalty + tdp, :140
+        const bool b_first = ef_cur[cls] < p1;                // is that source visited before the in-word ones?
+        mg.offer(b_first ? c_b : kInf, am_b, bkp_new);
+        mg.offer(c_skip, am, bk[p2]);
+        mg.offer(c_fwd, am, bk[p1]);
+        mg.offer(c_loop, am, bk[p]);
+        mg.offer(b_first ? kInf : c_b, am_b, bkp_new);
+      }
+      double lo = mg.score;
+      if (inf & kSlotSingle) {  // one-position word: its dead position-1 slot still feeds best_score (:139,155)
+        const double t_d = (inf & kSlotFirstSil) ? tf : ts;
+        double extra;
+        if (am >= 0.0) extra = ((m_we + wp) + t_d) + am;
+        else { extra = replay_boundary(a.net.word_end_slot, a.net.n_words, sc, bk, p, false, false, false, wp, t_d, am, am, tf, tf, bkp_new).score; slow_taken = 1; }
+        lo = extra < lo ? extra : lo;
+      }
+      my_best = lo < my_best ? lo : my_best;
+      scn[p] = mg.score;
+      bkn[p] = (uint16_t)mg.bkp;
+      if ((inf & kSlotEnd) && (mg.score < my_we || (mg.score == my_we && p < my_we_idx))) { my_we = mg.score; my_we_idx = p; }
+    }
+    if (tid < 4) ef_nxt[tid] = 0xFFFFFFFFu;
+    // ---- B ---------------------------------------------------------------------------------------------------------
+    my_best = wave_min(my_best);
+    wave_min_idx(my_we, my_we_idx);
+    if (lane == 0) { red_best[wave] = my_best; red_we[wave] = my_we; red_idx[wave] = my_we_idx; }
+    __syncthreads();
+    double best = red_best[0], we = red_we[0];
+    uint32_t we_idx = red_idx[0];
+#pragma unroll
+    for (uint32_t w = 1; w < kWavesPerWg; w++) {
+      const double ob = red_best[w];
+      best = ob < best ? ob : best;
+      const double ow = red_we[w];
+      const uint32_t oi = red_idx[w];
+      if (ow < we || (ow == we && oi < we_idx)) { we = ow; we_idx = oi; }
+    }
+    // ---- C: prune, traceback, publish the word-end minimum -----------------------------------------------------------
+    const double limit = best + thr;
+    const bool we_alive = !(we > limit) && we != kInf;
+    m_we = we_alive ? we : kInf;
+    const double near = m_we + (fabs(m_we) + fabs(wp_word) + fabs(tf) + fabs(ts) + 1.0) * 1e-9;
+    for (uint32_t p = tid; p < P; p += NT) {  // (a thread prunes the slots it wrote)
+      const double v = scn[p];
+      if (v > limit) { scn[p] = kInf; continue; }  // :194-196
+      if ((a.net.slot_info[p] & kSlotEnd) && we_alive && v <= near) {
+        if (p == we_idx) { a.tb_score[tb0 + t] = v; a.tb_word[tb0 + t] = (uint16_t)p; a.tb_bkp[tb0 + t] = bkn[p]; }
+        if (v + 0.0 + tf == m_we + 0.0 + tf) atomicMin(&ef_nxt[0], p);
+        if (v + 0.0 + ts == m_we + 0.0 + ts) atomicMin(&ef_nxt[1], p);
+        if (v + wp_word + tf == m_we + wp_word + tf) atomicMin(&ef_nxt[2], p);
+        if (v + wp_word + ts == m_we + wp_word + ts) atomicMin(&ef_nxt[3], p);
+      }
+    }
+    if (!we_alive && tid == 0) { a.tb_score[tb0 + t] = kInf; a.tb_word[tb0 + t] = 0xFFFFu; a.tb_bkp[tb0 + t] = 0; }
+    __syncthreads();  // workgroup-scope release/acquire: the pruned scores are visible to every thread of the next frame
+  }
+
+  // ---- traceback (Recognizer.cpp:222-231) -------------------------------------------------------------
+  __threadfence();
+  __syncthreads();
+  for (uint32_t t = 1 + tid; t <= T; t += NT) {
+    const uint32_t sl = __hip_atomic_load(&a.tb_word[tb0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a.tb_word[tb0 + t] = sl == 0xFFFFu ? (uint16_t)0 : (uint16_t)a.net.slot_word[sl];
+  }
+  __threadfence();
+  __syncthreads();
+  if (slow_taken) atomicOr(&a.out_flags[u], 1u);
+  if (tid == 0) {
+    uint32_t* words = a.out_words + f0;
+    uint32_t n = 0, t = T;
+    while (t > 0) {
+      const uint32_t w = __hip_atomic_load(&a.tb_word[tb0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (w != a.net.silence_word) words[n++] = w;
+      t = __hip_atomic_load(&a.tb_bkp[tb0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (uint32_t i = 0; i < n / 2; i++) { const uint32_t x = words[i]; words[i] = words[n - 1 - i]; words[n - 1 - i] = x; }
+    a.out_count[u] = n;
+  }
+}
+
+uint32_t decode_big_max_slots() { return 65534; }  // slot ids are 16 bit in the traceback, 0xFFFF = no surviving word end
+size_t decode_big_workspace(uint32_t n_slots) { return (((size_t)n_slots * 20) + 255) & ~(size_t)255; }  // per utterance in flight
+hipError_t launch_decode_big(const DecodeArgs& a, unsigned char* ws, hipStream_t stream) {
+  if (a.n_utts == 0) return hipSuccess;
+  if (a.net.n_slots > decode_big_max_slots() || !ws) return hipErrorInvalidValue;
+  hipLaunchKernelGGL((decode_big_kernel<1024>), dim3(a.n_utts), dim3(1024), 0, stream, a, ws, decode_big_workspace(a.net.n_slots));
+  return hipGetLastError();
+}
+
 uint32_t decode_max_slots() { return 8192; }
 
 static size_t decode_smem(uint32_t PP) { return (size_t)PP * 16 + 16 * 8 * 2 + 16 * 4 + 12 * 4 + (size_t)PP * 2 + 16; }
