@@ -417,7 +417,7 @@ static constexpr int kRThreads = SR_R_THREADS;   // 3 waves per SIMD; the regist
 static constexpr int kRWaves = kRThreads / 64;
 static constexpr int kRBatch = SR_R_BATCH;       // dimensions per software-pipeline stage of the candidate evaluation
 #ifndef SR_R_EXP
-#define SR_R_EXP 0   // timing experiments only (tools/build_variant.py, profiles/r2_refine_decomposition.txt): 1 = main pass
+#define SR_R_EXP 0   // timing experiments only (tools/build_variant.py, profiles/r2_refine_decomposition.txt): 2 = main pass + list appends, 1 = main pass
                      // alone (wrong scores), 5 = main pass without its LDS reads, 6 = main pass without its arithmetic
 #endif
 static constexpr uint32_t kRingEntries = 128;    // per (wave, level, state): < 64 pending + <= 64 appended per iteration
@@ -655,6 +655,7 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
     // table stores issued after the last list store (wave-uniform): SPW/2 row pieces, unless the data-dependent paths ran
     uint32_t tail_stores = (!chunk_shift && ns == SPW && __any(valid)) ? (uint32_t)(SPW / 2) : 0u;
     for (;;) {
+      if (SR_R_EXP == 2) { cnt1 &= 0x3F3F3F3F3F3F3F3Full; break; }  // main pass + appends, lists never worked off
       uint32_t level, j, n;
       {
         const uint64_t full1 = cnt1 & 0x4040404040404040ull, full2 = cnt2 & 0x4040404040404040ull;
