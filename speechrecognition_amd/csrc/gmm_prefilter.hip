@@ -422,7 +422,8 @@ static constexpr int kRBatch = SR_R_BATCH;       // dimensions per software-pipe
 #endif
 static constexpr uint32_t kRingEntries = 128;    // per (wave, level, state): < 64 pending + <= 64 appended per iteration
 static constexpr uint32_t kRingLists = 2 * 8 * kRingEntries;  // entries per wave: [level][state][128]
-static constexpr uint32_t kRingWave = 4 * kRingLists;         // u32 per wave: frame ids, remaining masks, best scores (f64)
+static constexpr uint32_t kRingWave = 4 * kRingLists;         // u32 per wave: 16-byte entries
+struct __attribute__((aligned(16))) RingEntry { uint32_t lf, mask; double score; };  // frame, candidates left, best score so far: one 16-byte store / load
 struct __attribute__((packed, aligned(4))) RowPiece { float v[4]; };  // 16 bytes of a feature row (rows are 4-byte aligned)
 
 template <int DT, int NS, int SPW>  // DT = compile-time feature dimension (0: run-time a.dim, features re-read from featsT)
@@ -570,9 +571,8 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
   // ---- wave-private candidate lists (global memory, a few KB per wave: L1/L2 resident) -----------------------------
   // an entry = (frame, candidates still to evaluate, best score so far): the batches need no look-up in the mask array or
   // the score table, they only store to the table where a later candidate wins
-  uint32_t* ring = a.ring + ((uint64_t)(blockIdx.y * gridDim.x + blockIdx.x) * kRWaves + wave) * kRingWave;
-  uint32_t* ring_mk = ring + kRingLists;
-  double* ring_sc = reinterpret_cast<double*>(ring + 2 * kRingLists);
+  RingEntry* ring = reinterpret_cast<RingEntry*>(a.ring + ((uint64_t)(blockIdx.y * gridDim.x + blockIdx.x) * kRWaves + wave) * kRingWave);
+  const bool counting = a.n_refined != nullptr;  // (kernel argument: a scalar branch around the bookkeeping)
   uint64_t cnt1 = 0, cnt2 = 0;  // eight 8-bit counters each (wave-uniform): frames pending per state, level 1 / level 2
   const uint64_t f_wave = f_begin + (uint64_t)wave * 64;
   auto frame_of = [&](uint32_t lf) -> uint64_t { return f_wave + (uint64_t)(lf >> 6) * kRThreads + (lf & 63u); };
@@ -601,7 +601,7 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
         if (n) {        // wave-uniform (a state without densities has an empty mask and keeps the seed)
           const double score = evaluate(panel_raw + (size_t)j * state_bytes + ((__builtin_ctz(mask | 0x80000000u) + s0 + j) & (NS - 1)) * 8u);
           if (mask != 0 && score < res[j]) res[j] = score;
-          n_eval += (valid && mask != 0) ? 1u : 0u;
+          if (counting) n_eval += (valid && mask != 0) ? 1u : 0u;
         }
         const bool more = valid && (mask & (mask - 1)) != 0;
         const uint64_t b = (SR_R_EXP == 1 || SR_R_EXP >= 5) ? 0 : __ballot(more);
@@ -609,9 +609,7 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
           const uint32_t c1 = (uint32_t)(cnt1 >> (8 * j)) & 0xFFu;
           const uint32_t pos = c1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
           if (more) {
-            ring[(uint32_t)j * kRingEntries + pos] = lf;
-            ring_mk[(uint32_t)j * kRingEntries + pos] = mask & (mask - 1);
-            ring_sc[(uint32_t)j * kRingEntries + pos] = res[j];
+            ring[(uint32_t)j * kRingEntries + pos] = RingEntry{lf, mask & (mask - 1), res[j]};
           }
           cnt1 += (uint64_t)__builtin_popcountll(b) << (8 * j);
         }
@@ -686,9 +684,10 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
       else __builtin_amdgcn_s_waitcnt(0x0F70);                                                  // vmcnt(0)
       asm volatile("" ::: "memory");
       const uint32_t at = slot0 + have - n + (live ? (uint32_t)lane : 0u);
-      const uint32_t lfb = ring[at];
-      uint32_t m = live ? ring_mk[at] : 0u;
-      double cur = ring_sc[at];
+      const RingEntry en = ring[at];
+      const uint32_t lfb = en.lf;
+      uint32_t m = live ? en.mask : 0u;
+      double cur = en.score;
       const uint64_t fb = frame_of(lfb);
       load_x_row(fb);
       double* o = a.out + fb * a.ld + ((s0 + j) >> chunk_shift);
@@ -699,7 +698,7 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
       const unsigned char* panel = panel_raw + (size_t)j * state_bytes;
       do {  // level 1: exactly one round (every live lane has a second candidate); level 2: until every lane is done
         const double score = evaluate(panel + ((__builtin_ctz(m | 0x80000000u) + s0 + j) & (NS - 1)) * 8u);
-        if (m != 0) { n_eval++; if (score < cur) cur = score; }
+        if (m != 0) { if (counting) n_eval++; if (score < cur) cur = score; }
         m &= m - 1;
       } while (!l1 && __any(m != 0));
       if (l1) {
@@ -708,9 +707,7 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
           const uint32_t c2 = (uint32_t)(cnt2 >> (8u * j)) & 0xFFu;
           const uint32_t pos = c2 + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
           if (m != 0) {
-            ring[(8u + j) * kRingEntries + pos] = lfb;
-            ring_mk[(8u + j) * kRingEntries + pos] = m;
-            ring_sc[(8u + j) * kRingEntries + pos] = cur;
+            ring[(8u + j) * kRingEntries + pos] = RingEntry{lfb, m, cur};
           }
           cnt2 += (uint64_t)__builtin_popcountll(b) << (8u * j);
         }
