@@ -429,11 +429,16 @@ int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm
 struct Chunk { uint32_t u0, u1; uint64_t f0, f1; };
 std::vector<Chunk> make_chunks(const sr_corpus* c, size_t chunk_frames) {
   std::vector<Chunk> out;
-
+  // chunks of whole utterances, at most chunk_frames each (a longer utterance is a chunk of its own), and of about equal size
+  // when several are needed: the search of chunk i runs beside the scoring of chunk i+1, and a short last chunk leaves the
+  // long one's search without company (configs[4]: 147 ms per step with 16 + 3.4 GB chunks, 138.5 with 2 x 9.7)
+  const uint64_t total = c->n_frames;
+  const uint64_t n_target = std::max<uint64_t>(1, (total + chunk_frames - 1) / std::max<size_t>(1, chunk_frames));
+  const uint64_t even = (total + n_target - 1) / n_target;
   uint32_t u = 0;
   while (u < c->n_utts) {
     uint32_t v = u + 1;
-    while (v < c->n_utts && c->frame_off[v + 1] - c->frame_off[u] <= chunk_frames) v++;
+    while (v < c->n_utts && c->frame_off[v + 1] - c->frame_off[u] <= chunk_frames && c->frame_off[v] - c->frame_off[u] < even) v++;
     out.push_back({u, v, c->frame_off[u], c->frame_off[v]});
     u = v;
   }
@@ -551,10 +556,16 @@ int model_shell(int device, uint32_t dim, uint32_t n_states, const uint32_t* den
   m->max_dens = std::max(1u, mx);
   m->h_dens_off.assign(dens_off, dens_off + n_states + 1);
   const char* env = getenv("SRGPU_SCORE_CHUNK_MB");
-  // score workspace per chunk: 16 GiB by default (two such buffers only when a corpus needs more than one
-  // chunk).  Bigger chunks mean fewer, longer GMM launches -- measured 68 vs 65 TFLOP/s at 4 GiB -- and
-  // MI355X has 288 GB of HBM to spend.
-  const size_t chunk_bytes = (env ? (size_t)atol(env) : 16384) << 20;
+  // score workspace per chunk: 48 GiB by default, at most a sixth of the device's memory (two such buffers only when a
+  // corpus needs more than one chunk, and the candidate masks of a chunk take up to as much again).  Bigger chunks mean
+  // fewer, longer launches (configs[4]'s 19.4 GB table: 136.8 ms per step in one chunk, 147.1 in 16 + 3.4 GB) and MI355X has
+  // 288 GB of HBM to spend.
+  size_t chunk_bytes = (size_t)49152 << 20;
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) chunk_bytes = std::min(chunk_bytes, total_b / 6);
+  }
+  if (env) chunk_bytes = (size_t)atol(env) << 20;
   m->chunk_frames = std::max<size_t>(1, chunk_bytes / ((size_t)m->ld * sizeof(double)));
   // the refinement kernel addresses the transposed feature copy of a chunk with 32-bit buffer offsets
   m->chunk_frames = std::min<size_t>(m->chunk_frames, ((size_t)1 << 32) / (4 * (size_t)dim) - 128);
