@@ -26,7 +26,7 @@ for case in range(n_cases):
     mp = os.path.join(tmp, "m.mix")
     synth.write_mixset(mp, spec)
     beam = float(rng.choice([15.0, 60.0, 200.0, 1e9]))
-    n_utts = int(rng.choice([1, 3, 9, 140]))
+    n_utts = int(rng.choice([1, 3, 9, 140, 300]))
     lens = rng.integers(1, 40, size=n_utts)
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
     feats = (float(rng.choice([1.0, 3.0])) * rng.standard_normal((int(off[-1]), D))).astype(np.float32)
