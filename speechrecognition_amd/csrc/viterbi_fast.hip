@@ -109,6 +109,9 @@ static constexpr uint32_t kKindMask = 7u;
 static constexpr uint32_t kE0 = 0, kE0S = 1, kE1 = 2, kE1E = 3, kM = 4, kME = 5, kPad = 6;
 static constexpr uint32_t kTSilState = 8u, kTSilWord = 16u, kTFirstSil = 32u;
 
+template <uint32_t K> struct KindC { __device__ constexpr operator uint32_t() const { return K; } };  // a slot kind known at compile time
+struct KindR { uint32_t v; __device__ operator uint32_t() const { return v; } };                          // ... or only at run time
+
 template <int NT, int SPT>
 __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -149,6 +152,9 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
     ty[i] = __builtin_amdgcn_readfirstlane(in ? net.chunk_type[p >> 6] : kPad);  // one type per 64-slot chunk
     sc[p] = kInfF; bk[p] = 0;
   }
+  bool uniform_kind = true;  // wave-uniform: all of this wave's chunks have the same type word
+#pragma unroll
+  for (int i = 1; i < SPT; i++) uniform_kind &= ty[i] == ty[0];
   bool wave_has_we = false;  // wave-uniform: does any of this wave's chunks hold word-end slots?
 #pragma unroll
   for (int i = 0; i < SPT; i++) {
@@ -194,12 +200,9 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
     double my_best = kInfF, my_we = kInfF;
     uint32_t my_we_idx = 0xFFFFFFFFu;
     bool neg = false;
-#pragma unroll
-    for (int i = 0; i < SPT; i++) {
+    // one slot's candidates; `kind` is wave-uniform -- a run-time scalar (KindR) or a compile-time constant (KindC)
+    auto slot_a = [&](const auto kind, const uint32_t type, const int i) __attribute__((always_inline)) {
       const uint32_t p = slot_of(i);
-      const uint32_t type = ty[i], kind = type & kKindMask;
-      nv[i] = kInfF; nb[i] = 0;
-      if (kind == kPad) continue;  // wave-uniform
       const double am = am_l[p];
       neg |= am < 0.0;
       const bool sil = type & kTSilState;
@@ -251,6 +254,30 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
         const uint32_t o = og[i] & 0xFFFFu;
         if (real && (v < my_we || (v == my_we && o < my_we_idx))) { my_we = v; my_we_idx = o; }
       }
+    };
+    if (uniform_kind) {
+      // All SPT chunks of this wave are of one kind (the throughput layout deals consecutive chunks of the type-sorted net):
+      // one scalar branch, then the SPT slots as straight-line code whose LDS reads and FP64 chains interleave -- per slot
+      // the loop is a dependent chain, and four waves per SIMD do not hide it
+#pragma unroll
+      for (int i = 0; i < SPT; i++) { nv[i] = kInfF; nb[i] = 0; }
+      switch (ty[0] & kKindMask) {
+#define SR_KIND_CASE(K)                                                   \
+        case K:                                                           \
+          _Pragma("unroll") for (int i = 0; i < SPT; i++) slot_a(KindC<K>{}, ty[0], i); \
+          break;
+        SR_KIND_CASE(kE0) SR_KIND_CASE(kE0S) SR_KIND_CASE(kE1) SR_KIND_CASE(kE1E) SR_KIND_CASE(kM) SR_KIND_CASE(kME)
+#undef SR_KIND_CASE
+        default: break;  // kPad
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < SPT; i++) {
+        const uint32_t type = ty[i], kind = type & kKindMask;
+        nv[i] = kInfF; nb[i] = 0;
+        if (kind == kPad) continue;  // wave-uniform
+        slot_a(KindR{kind}, type, i);
+      }
     }
     if (neg) *bail = 1;
     if (tid < 4) ef_nxt[tid] = 0xFFFFFFFFu;
@@ -281,22 +308,29 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
     m_we = we_alive ? we : kInfF;
     const double near = m_we + (fabs(m_we) + fabs(wp_word) + fabs(tf) + fabs(ts) + 1.0) * 1e-9;
 #pragma unroll
-    for (int i = 0; i < SPT; i++) {
+    for (int i = 0; i < SPT; i++) {  // the stores of all slots first: straight-line
       const uint32_t p = slot_of(i);
-      const uint32_t kind = ty[i] & kKindMask;
       double v = nv[i];
       if (v > limit) v = kInfF;  // :194-196
+      nv[i] = v;
       sc[p] = v;
       bk[p] = (uint16_t)nb[i];
       am_l[p] = am_n[i];
-      if (kind == kE0S || kind == kE1E || kind == kME) {
-        if (we_alive && v <= near) {
-          const uint32_t o = og[i] & 0xFFFFu;
-          if (o == we_idx) { a.tb_score[tb0 + t] = v; a.tb_word[tb0 + t] = (uint16_t)p; a.tb_bkp[tb0 + t] = (uint16_t)nb[i]; }
-          if (v + 0.0 + tf == m_we + 0.0 + tf) atomicMin(&ef_nxt[0], o);
-          if (v + 0.0 + ts == m_we + 0.0 + ts) atomicMin(&ef_nxt[1], o);
-          if (v + wp_word + tf == m_we + wp_word + tf) atomicMin(&ef_nxt[2], o);
-          if (v + wp_word + ts == m_we + wp_word + ts) atomicMin(&ef_nxt[3], o);
+    }
+    if (wave_has_we && we_alive) {  // wave-uniform
+#pragma unroll
+      for (int i = 0; i < SPT; i++) {
+        const uint32_t kind = ty[i] & kKindMask;
+        if (kind == kE0S || kind == kE1E || kind == kME) {
+          const double v = nv[i];
+          if (v <= near) {
+            const uint32_t p = slot_of(i), o = og[i] & 0xFFFFu;
+            if (o == we_idx) { a.tb_score[tb0 + t] = v; a.tb_word[tb0 + t] = (uint16_t)p; a.tb_bkp[tb0 + t] = (uint16_t)nb[i]; }
+            if (v + 0.0 + tf == m_we + 0.0 + tf) atomicMin(&ef_nxt[0], o);
+            if (v + 0.0 + ts == m_we + 0.0 + ts) atomicMin(&ef_nxt[1], o);
+            if (v + wp_word + tf == m_we + wp_word + tf) atomicMin(&ef_nxt[2], o);
+            if (v + wp_word + ts == m_we + wp_word + ts) atomicMin(&ef_nxt[3], o);
+          }
         }
       }
     }
