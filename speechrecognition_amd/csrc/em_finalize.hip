@@ -19,7 +19,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <atomic>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -74,6 +76,31 @@ __global__ void fin_expand_kernel(const double* means, const double* ivars, cons
   means_e[i] = means[(uint64_t)dens_mean[c] * D + d];
   ivars_e[i] = ivars[(uint64_t)dens_var[c] * D + d];
 }
+
+// One pinned host buffer for the process, grown on demand and kept: hipHostMalloc costs milliseconds, an EM loop calls
+// finalize once per iteration.  A lease holds the buffer's mutex (finalize calls of several device threads take turns).
+struct PinnedScratch {
+  std::mutex mu;
+  void* p = nullptr;
+  size_t bytes = 0;
+  static PinnedScratch& instance() { static PinnedScratch s; return s; }
+  struct Lease {
+    PinnedScratch& s;
+    void* ptr = nullptr;
+    Lease(PinnedScratch& s_, size_t need) : s(s_) {
+      s.mu.lock();
+      if (need > s.bytes) {
+        if (s.p) (void)hipHostFree(s.p);
+        s.p = nullptr; s.bytes = 0;
+        void* q = nullptr;
+        if (hipHostMalloc(&q, need, hipHostMallocPortable) == hipSuccess) { s.p = q; s.bytes = need; }
+        else (void)hipGetLastError();
+      }
+      ptr = s.p;
+    }
+    ~Lease() { s.mu.unlock(); }
+  };
+};
 
 template <typename T>
 hipError_t to_device(DevBuf<T>& b, const T* src, size_t n) { return b.upload(src, n); }
@@ -169,18 +196,58 @@ static int finalize_core(int device, uint32_t dim, uint32_t n_states, const uint
   if (C) hipLaunchKernelGGL(fin_expand_kernel, grid_for(C * D), dim3(256), 0, st, d_means.p, d_ivars.p, m->dens_mean.p, m->dens_var.p, C, D, m->means.p, m->inv_vars.p);
   HIP_TRY(hipGetLastError());
 
-  // ---- host: the logarithms (libm: the reference's bits), on the variances the device computed ----------------------
-  std::vector<double> vars((size_t)n_var * D), norm_row(n_var, 0.0);
-  HIP_TRY(hipStreamSynchronize(st));
-  if (n_var) HIP_TRY(hipMemcpy(vars.data(), d_vars.p, vars.size() * sizeof(double), hipMemcpyDeviceToHost));
-  spread(n_var, [&](size_t j0, size_t j1) {
-    for (size_t j = j0; j < j1; j++) {
-      if (var_src[j] == kNoWriter) continue;  // norm_ stays 0
-      double acc = D * log(2 * M_PI);
-      for (uint32_t d = 0; d < D; d++) acc = acc + log(vars[j * D + d]);
-      norm_row[j] = acc / 2;
+  // ---- host: the logarithms (libm: the reference's bits), on the variances the device computed.  The variances come back
+  // in pieces through a pinned buffer kept for the process (pageable memory, zero-filled first, made this the longest part of
+  // an EM iteration), and every host thread starts on a piece as soon as its copy has landed ----------------------------
+  std::vector<double> norm_row(n_var, 0.0);
+  if (n_var) {
+    PinnedScratch::Lease lease(PinnedScratch::instance(), (size_t)n_var * D * sizeof(double));
+    const double* vars = static_cast<const double*>(lease.ptr);
+    constexpr int kPieces = 8;
+    hipEvent_t ev[kPieces];
+    size_t row_lo[kPieces + 1];
+    for (int k = 0; k <= kPieces; k++) row_lo[k] = (size_t)n_var * k / kPieces;
+    bool pinned = vars != nullptr;
+    std::vector<double> pageable;
+    if (!pinned) {  // no pinned memory to be had: one blocking copy into ordinary memory
+      pageable.resize((size_t)n_var * D);
+      HIP_TRY(hipStreamSynchronize(st));
+      HIP_TRY(hipMemcpy(pageable.data(), d_vars.p, pageable.size() * sizeof(double), hipMemcpyDeviceToHost));
+      vars = pageable.data();
+    } else {
+      for (int k = 0; k < kPieces; k++) {
+        HIP_TRY(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+        const size_t off = row_lo[k] * D, cnt = (row_lo[k + 1] - row_lo[k]) * D;
+        if (cnt) HIP_TRY(hipMemcpyAsync(const_cast<double*>(vars) + off, d_vars.p + off, cnt * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(ev[k], st));
+      }
     }
-  });
+    std::atomic<int> failed{0};
+    auto rows = [&](size_t t, size_t nt) {
+      for (int k = 0; k < kPieces; k++) {
+        if (pinned && hipEventSynchronize(ev[k]) != hipSuccess) { failed = 1; return; }
+        const size_t n = row_lo[k + 1] - row_lo[k], j0 = row_lo[k] + n * t / nt, j1 = row_lo[k] + n * (t + 1) / nt;
+        for (size_t j = j0; j < j1; j++) {
+          if (var_src[j] == kNoWriter) continue;  // norm_ stays 0
+          double acc = D * log(2 * M_PI);
+          for (uint32_t d = 0; d < D; d++) acc = acc + log(vars[j * D + d]);
+          norm_row[j] = acc / 2;
+        }
+      }
+    };
+    if (n_threads <= 1 || n_var < 1024) {
+      rows(0, 1);
+    } else {
+      std::vector<std::thread> pool;
+      for (size_t t = 0; t < n_threads; t++) pool.emplace_back(rows, t, n_threads);
+      for (auto& th : pool) th.join();
+    }
+    if (pinned)
+      for (int k = 0; k < kPieces; k++) (void)hipEventDestroy(ev[k]);
+    if (failed) return fail(SR_EHIP, "finalize: waiting for the variances failed");
+  } else {
+    HIP_TRY(hipStreamSynchronize(st));
+  }
   std::vector<double> norm_e(C);
   for (uint64_t c = 0; c < C; c++) norm_e[c] = norm_row[dens_var[c]];
   if (C) {
