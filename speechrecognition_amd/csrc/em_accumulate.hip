@@ -12,7 +12,7 @@
 //   2. a STABLE radix sort of the pairs by mean index (and again by variance index: tied variances are summed
 //      across the densities sharing them, in frame order);
 //   3. em_bounds_kernel   first pair of every accumulator row (binary search per row), then
-//      em_sum_kernel      one thread per (row, dimension) walks the row's pairs in order:
+//      em_sum_kernel      one wave per row (a lane per dimension) walks the row's pairs in order:
 //                         mean_acc += w*x, var_acc += (w*x)*x (starting at 1e-4, :243), weight += w.
 // Parallelism is across rows (10^5 of them), never inside a row.  Soft mode uses the device exp, so its
 // weights differ from glibc's by an ulp or two: tolerance 1e-12 there, bit-exact otherwise.
@@ -132,40 +132,65 @@ __global__ __launch_bounds__(256) void em_bounds_kernel(const uint32_t* sorted_k
   row_begin[row] = (uint32_t)lo;
 }
 
-// one thread per (accumulator row, dimension), rows' pairs walked in order; SQUARE: variance statistics
+// One WAVE per accumulator row, a lane per dimension; SQUARE: variance statistics.  The additions of a row must stay in corpus
+// order (bit-exactness), so a row is never split -- but a row that collects tens of thousands of frames (silence) is bound by
+// memory round trips, not by its chain of additions: the wave fetches the row's pairs 64 at a time (ids, then weights and
+// frames: one lane each, the next batch while this one is summed), hands them round through a wave-private LDS slot array (broadcast
+// reads), and keeps 16 feature rows (156 contiguous bytes each) in flight.  (One thread per (row, dimension) walking the list by itself: 14 ms for the
+// variance sums of the bench model against 4.5 with its loads staged 16 at a time and 1.x this way.)
 template <bool SQUARE>
 __global__ __launch_bounds__(256) void em_sum_kernel(EmArgs a, const uint32_t* row_begin, const uint32_t* sorted_pairs,
                                                      uint32_t n_rows, double* acc, double* weight) {
-  const uint32_t D = a.dim;
-  const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const uint32_t row = (uint32_t)(idx / D), d = (uint32_t)(idx % D);
-  if (row >= n_rows) return;
+  const uint32_t D = a.dim, lane = threadIdx.x & 63u;
+  const uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (row >= n_rows) return;  // wave-uniform
   const uint32_t lo = row_begin[row], e = row_begin[row + 1];
-  double sum = SQUARE ? 1e-4 : 0.0;  // reset_accumulators: variances start at minimal_variance_value_ (:167,243)
-  double w = 0.0;
-  // The additions must stay in corpus order (bit-exactness), but the operands of many pairs can be in flight at
-  // once: a row that collects tens of thousands of frames (silence) is then bound by the add chain, not by three
-  // dependent loads per frame.
-  for (uint32_t i = lo; i < e; i += 16) {
-    double pp[16], yy[16];
+  constexpr int kF = 16;  // feature rows in flight
+  __shared__ ulonglong2 slots[4][64];
+  ulonglong2* slot = slots[threadIdx.x >> 6];  // wave-private: (feature row offset, weight) of the batch's pairs
+  for (uint32_t d0 = 0; d0 < D; d0 += 64) {  // (one pass for D <= 64)
+    const uint32_t d = d0 + lane;
+    const bool act = d < D;
+    const float* col = a.feats + (act ? d : 0u);
+    double sum = SQUARE ? 1e-4 : 0.0;  // reset_accumulators: variances start at minimal_variance_value_ (:167,243)
+    double w = 0.0;
+    // batch metadata of this lane: pair lo + lane of the current batch
+    auto meta = [&](uint32_t i, double& pw, uint32_t& fr) {
+      const uint32_t pr = sorted_pairs[(i + lane < e) ? i + lane : (e ? e - 1 : 0u)];
+      pw = a.pair_w[pr];
+      fr = a.pair_frame[pr];
+    };
+    double pw = 0.0, pw_n = 0.0;
+    uint32_t fr = 0, fr_n = 0;
+    if (lo < e) meta(lo, pw, fr);
+    for (uint32_t i = lo; i < e; i += 64) {
+      const uint32_t n = (e - i < 64u) ? e - i : 64u;
+      if (i + 64 < e) meta(i + 64, pw_n, fr_n);  // the next batch's metadata travels while this batch is summed
+      // this lane's pair to the wave's LDS slots: the loop below reads element j from ONE address (a broadcast read)
+      // instead of three v_readlane + the offset multiplication per element
+      slot[lane] = make_ulonglong2((unsigned long long)fr * D, (unsigned long long)__double_as_longlong(pw));
+      for (uint32_t j0 = 0; j0 < n; j0 += kF) {  // wave-uniform
+        double yy[kF], ww[kF];
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const uint32_t ij = (i + j < e) ? i + j : i;
-      const uint32_t pair = sorted_pairs[ij];
-      pp[j] = a.pair_w[pair];
-      yy[j] = (double)a.feats[(uint64_t)a.pair_frame[pair] * D + d];
-    }
+        for (int j = 0; j < kF; j++) {
+          const ulonglong2 m = slot[(j0 + j < n) ? j0 + j : j0];
+          ww[j] = __longlong_as_double((long long)m.y);
+          yy[j] = (double)col[m.x];
+        }
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-      if (i + j < e) {
-        if (SQUARE) sum = sum + pp[j] * yy[j] * yy[j];  // scale_add_square: x + scale * y * y  (:56-64)
-        else sum = sum + pp[j] * yy[j];                 // scale_add:        x + scale * y      (:46-54)
-        w += pp[j];
+        for (int j = 0; j < kF; j++) {
+          if (j0 + j < n) {  // wave-uniform
+            if (SQUARE) sum = sum + ww[j] * yy[j] * yy[j];  // scale_add_square: x + scale * y * y  (:56-64)
+            else sum = sum + ww[j] * yy[j];                 // scale_add:        x + scale * y      (:46-54)
+            w += ww[j];
+          }
+        }
       }
+      pw = pw_n; fr = fr_n;
     }
+    if (act) acc[(uint64_t)row * D + d] = sum;
+    if (d0 == 0 && lane == 0) weight[row] = w;
   }
-  acc[(uint64_t)row * D + d] = sum;
-  if (d == 0) weight[row] = w;
 }
 
 size_t em_sort_temp_bytes(uint64_t n_pairs) {
@@ -187,13 +212,13 @@ hipError_t launch_em_accumulate(const EmArgs& a, void* sort_temp, size_t sort_te
   e = hipcub::DeviceRadixSort::SortPairs(sort_temp, sort_temp_bytes, a.key_mean, keys_sorted, iota, pairs_sorted, (int)a.n_pairs, 0, 32, stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(em_bounds_kernel, dim3(a.n_mean / 256 + 1), dim3(256), 0, stream, keys_sorted, a.n_pairs, a.n_mean, row_begin);
-  hipLaunchKernelGGL((em_sum_kernel<false>), dim3((unsigned)(((uint64_t)a.n_mean * a.dim + 255) / 256)), dim3(256), 0, stream, a,
+  hipLaunchKernelGGL((em_sum_kernel<false>), dim3((a.n_mean + 3) / 4), dim3(256), 0, stream, a,
                      row_begin, pairs_sorted, a.n_mean, mean_acc, mean_w);
   if ((e = hipGetLastError()) != hipSuccess) return e;
   e = hipcub::DeviceRadixSort::SortPairs(sort_temp, sort_temp_bytes, a.key_var, keys_sorted, iota, pairs_sorted, (int)a.n_pairs, 0, 32, stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(em_bounds_kernel, dim3(a.n_var / 256 + 1), dim3(256), 0, stream, keys_sorted, a.n_pairs, a.n_var, row_begin);
-  hipLaunchKernelGGL((em_sum_kernel<true>), dim3((unsigned)(((uint64_t)a.n_var * a.dim + 255) / 256)), dim3(256), 0, stream, a,
+  hipLaunchKernelGGL((em_sum_kernel<true>), dim3((a.n_var + 3) / 4), dim3(256), 0, stream, a,
                      row_begin, pairs_sorted, a.n_var, var_acc, var_w);
   return hipGetLastError();
 }

@@ -20,6 +20,9 @@
 
 #include <cmath>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -117,6 +120,16 @@ static int finalize_core(int device, uint32_t dim, uint32_t n_states, const uint
                          const uint32_t* dens_mean, const uint32_t* dens_var, const double* mean_acc, const double* mean_w,
                          const double* var_acc, const double* var_w, bool acc_on_device, int pooling, int max_approx, sr_model** out) {
   *out = nullptr;
+  static const bool fin_timing = getenv("SRGPU_FIN_TIMING") != nullptr;  // phase times to stderr (diagnostic)
+  auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_begin = now_ms();
+  double t_last = t_begin;
+  auto lap = [&](const char* what) {
+    if (!fin_timing) return;
+    const double t = now_ms();
+    fprintf(stderr, "[finalize] %-28s %7.2f ms\n", what, t - t_last);
+    t_last = t;
+  };
   if (!dens_off || !dens_mean || !dens_var || !mean_acc || !mean_w || !var_acc || !var_w) return fail(SR_EINVAL, "null argument");
   for (uint32_t s = 0; s < n_states; s++)
     if (dens_off[s + 1] < dens_off[s]) return fail(SR_EINVAL, "dens_off must be non-decreasing");
@@ -129,6 +142,7 @@ static int finalize_core(int device, uint32_t dim, uint32_t n_states, const uint
   std::unique_ptr<sr_model, int (*)(sr_model*)> own(m, sr_model_destroy);
   const uint32_t D = dim;
   hipStream_t st = m->s_gmm;
+  lap("checks + model shell");
 
   // ---- host: observation totals, last writers (integer work + C sequential additions) ------------------------------
   std::vector<double> mix_total(n_states, 0.0), logw_e(C, 0.0);
@@ -159,6 +173,7 @@ static int finalize_core(int device, uint32_t dim, uint32_t n_states, const uint
     for (size_t c = c0; c < c1; c++) logw_e[c] = log(mean_w[dens_mean[c]] / mix_total[mean_last[dens_mean[c]]]);
   });
 
+  lap("host totals + log weights");
   // ---- device: divisions, variances, per-density expansion -----------------------------------------------------------
   DevBuf<double> d_macc_own, d_mw, d_vacc_own, d_vw, d_means, d_vars, d_ivars, d_pooled, d_total;
   DevBuf<uint32_t> d_src, d_goff;
@@ -195,6 +210,7 @@ static int finalize_core(int device, uint32_t dim, uint32_t n_states, const uint
   if ((uint64_t)n_var * D) hipLaunchKernelGGL(fin_vars_kernel, grid_for((uint64_t)n_var * D), dim3(256), 0, st, d_vacc.p, d_vw.p, mu, d_src.p, n_var, D, d_vars.p, d_ivars.p);
   if (C) hipLaunchKernelGGL(fin_expand_kernel, grid_for(C * D), dim3(256), 0, st, d_means.p, d_ivars.p, m->dens_mean.p, m->dens_var.p, C, D, m->means.p, m->inv_vars.p);
   HIP_TRY(hipGetLastError());
+  lap("uploads + kernel launches");
 
   // ---- host: the logarithms (libm: the reference's bits), on the variances the device computed.  The variances come back
   // in pieces through a pinned buffer kept for the process (pageable memory, zero-filled first, made this the longest part of
@@ -248,12 +264,14 @@ static int finalize_core(int device, uint32_t dim, uint32_t n_states, const uint
   } else {
     HIP_TRY(hipStreamSynchronize(st));
   }
+  lap("variances back + logarithms");
   std::vector<double> norm_e(C);
   for (uint64_t c = 0; c < C; c++) norm_e[c] = norm_row[dens_var[c]];
   if (C) {
     HIP_TRY(hipMemcpy(m->norm.p, norm_e.data(), C * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(m->logw.p, logw_e.data(), C * sizeof(double), hipMemcpyHostToDevice));
   }
+  lap("norm gather + upload");
   *out = own.release();
   return SR_OK;
 }
