@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void em_bounds_kernel(const uint32_t* sorted_k
 // order (bit-exactness), so a row is never split -- but a row that collects tens of thousands of frames (silence) is bound by
 // memory round trips, not by its chain of additions: the wave fetches the row's pairs 64 at a time (ids, then weights and
 // frames: one lane each, the next batch while this one is summed), hands them round through a wave-private LDS slot array (broadcast
-// reads), and keeps 16 feature rows (156 contiguous bytes each) in flight.  (One thread per (row, dimension) walking the list by itself: 14 ms for the
+// reads), and keeps 32 feature rows (156 contiguous bytes each) in flight.  (One thread per (row, dimension) walking the list by itself: 14 ms for the
 // variance sums of the bench model against 4.5 with its loads staged 16 at a time and 1.x this way.)
 template <bool SQUARE>
 __global__ __launch_bounds__(256) void em_sum_kernel(EmArgs a, const uint32_t* row_begin, const uint32_t* sorted_pairs,
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void em_sum_kernel(EmArgs a, const uint32_t* r
   const uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6);
   if (row >= n_rows) return;  // wave-uniform
   const uint32_t lo = row_begin[row], e = row_begin[row + 1];
-  constexpr int kF = 16;  // feature rows in flight
+  constexpr int kF = 32;  // feature rows in flight
   __shared__ ulonglong2 slots[4][64];
   ulonglong2* slot = slots[threadIdx.x >> 6];  // wave-private: (feature row offset, weight) of the batch's pairs
   for (uint32_t d0 = 0; d0 < D; d0 += 64) {  // (one pass for D <= 64)
@@ -170,19 +170,16 @@ __global__ __launch_bounds__(256) void em_sum_kernel(EmArgs a, const uint32_t* r
       // instead of three v_readlane + the offset multiplication per element
       slot[lane] = make_ulonglong2((unsigned long long)fr * D, (unsigned long long)__double_as_longlong(pw));
       for (uint32_t j0 = 0; j0 < n; j0 += kF) {  // wave-uniform
-        double yy[kF], ww[kF];
+        double yy[kF];
 #pragma unroll
-        for (int j = 0; j < kF; j++) {
-          const ulonglong2 m = slot[(j0 + j < n) ? j0 + j : j0];
-          ww[j] = __longlong_as_double((long long)m.y);
-          yy[j] = (double)col[m.x];
-        }
+        for (int j = 0; j < kF; j++) yy[j] = (double)col[slot[(j0 + j < n) ? j0 + j : j0].x];
 #pragma unroll
         for (int j = 0; j < kF; j++) {
           if (j0 + j < n) {  // wave-uniform
-            if (SQUARE) sum = sum + ww[j] * yy[j] * yy[j];  // scale_add_square: x + scale * y * y  (:56-64)
-            else sum = sum + ww[j] * yy[j];                 // scale_add:        x + scale * y      (:46-54)
-            w += ww[j];
+            const double p = __longlong_as_double((long long)slot[j0 + j].y);
+            if (SQUARE) sum = sum + p * yy[j] * yy[j];  // scale_add_square: x + scale * y * y  (:56-64)
+            else sum = sum + p * yy[j];                 // scale_add:        x + scale * y      (:46-54)
+            w += p;
           }
         }
       }
