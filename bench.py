@@ -208,7 +208,7 @@ def main():
                 "shard_imbalance": max(shard_frames) / (sum(shard_frames) / world),  # heaviest shard / mean: what strong scaling can lose
             },
             "roofline": gmm_roofline(args, prof, n_frames, D, S),
-            "search": search_report(args, prof, S, int(word_off[-1]), n_frames),
+            "search": search_report(args, prof, S, int(word_off[-1]), padded_slots(word_off, automaton, lex.silence_idx, sil_state), n_frames, len(frame_off) - 1),
             "recognised_words_rank0": int(woff[-1]),
         }
         if args.kernel == "prefilter":
@@ -273,23 +273,46 @@ def gmm_roofline(args, prof, n_frames, D, S):
             "flops_per_frame": 4.0 * D * S * args.mix}
 
 
-def decode_geometry(P):
-    """threads x slots per thread of decode_fast_kernel for P type-padded trellis positions (launch_decode_fast)."""
-    for limit, geom in ((64, "64, 1"), (256, "64, 4"), (1024, "256, 4"), (2048, "256, 8"), (4096, "1024, 4"), (8192, "1024, 8")):
+def padded_slots(word_off, automaton, silence_idx, silence_state):
+    """Trellis positions after the fast decoder's type sort: every (kind, silence flags) group is padded to whole 64-slot
+    chunks (sr_lexicon_create: build of the type-sorted net)."""
+    import collections
+    groups = collections.Counter()
+    for w in range(len(word_off) - 1):
+        b, n = int(word_off[w]), int(word_off[w + 1] - word_off[w])
+        first = int(automaton[b])
+        for k in range(n):
+            kind = (1 if n == 1 else 0) if k == 0 else (3 if n == 2 else 2) if k == 1 else (5 if k == n - 1 else 4)
+            st = int(automaton[b + k])
+            groups[kind | (int(st == silence_state) << 3) | (int(w == silence_idx) << 4) | (int(first == silence_state) << 5)] += 1
+    return sum((c + 63) // 64 * 64 for c in groups.values())
+
+
+def decode_geometry(P, n_utts):
+    """threads x slots per thread of decode_fast_kernel for P type-padded trellis positions in a launch of n_utts utterances
+    (launch_decode_fast: the widest workgroup when there is at most one utterance per CU, narrower ones for throughput);
+    None beyond the LDS kernels' 8192 slots (decode_big_kernel)."""
+    if P > 8192:
+        return None
+    small = ((64, "64, 1"), (256, "256, 1"), (1024, "1024, 1"), (2048, "1024, 2")) if n_utts <= 256 else \
+            ((64, "64, 1"), (256, "64, 4"), (1024, "256, 4"), (2048, "512, 4"))
+    for limit, geom in small + ((4096, "1024, 4"), (8192, "1024, 8")):
         if P <= limit:
             return geom
-    return "?"
+    return None
 
 
-def search_report(args, prof, S, P, n_frames):
+def search_report(args, prof, S, P, P_padded, n_frames, n_utts):
     """The Viterbi step against SURVEY 8(d)'s HBM model (8*S + 4*P bytes per frame), next to what the counters say bounds
     it: the frame-sequential recursion issues ~100 vector + ~40 scalar instructions per slot and frame and keeps the SIMDs
     issuing in 98 % of the cycles (profiles/r2_decoder_one_barrier_experiment.txt) -- HBM is at a fifth of its peak."""
     ms = prof["search_ms"] / max(1, args.steps)
     algorithmic = prof["search_bytes"] / (prof["search_ms"] * 1e-3) / 1e9 if prof["search_ms"] > 0 else 0.0
     traffic = pmc_traffic(args, n_frames, "decode_fast_kernel")
+    geom = decode_geometry(P_padded, n_utts)
     return {
-        "kernel": f"decode_fast_kernel<{decode_geometry(((P + 63) // 64 + 3) * 64)}> (+ decode_kernel replay of flagged utterances)",
+        "kernel": (f"decode_fast_kernel<{geom}> (+ decode_kernel replay of flagged utterances)" if geom else
+                   "decode_big_kernel<1024> (hypotheses in device memory: more than 8192 type-padded slots)"),
         "ms_per_step": ms,
         "bound": "instruction issue (VALU+SALU active in ~98 % of the SIMD cycles); not HBM",
         "hbm_model": {"bytes_per_frame": 8.0 * S + 4.0 * P, "achieved_GBps": algorithmic, "peak_GBps": 8000.0, "frac": algorithmic / 8000.0},

@@ -397,7 +397,7 @@ hipError_t launch_decode_fast(const DecodeArgs& a, hipStream_t stream) {
   if (geom == 6404 && P <= 256) SR_LAUNCH(64, 4);
   if (a.n_utts <= 256) {
     // At most one utterance per CU: the frame loop is a chain of dependent steps, and the widest workgroup makes it shortest
-    // (one 10 000-frame utterance, us per frame: P = 1152: 3.11 at 256 x 8, 2.24 at 512 x 4, 1.98 at 1024 x 2; P = 448: 1.97 at
+    // (one 10 000-frame utterance, us per frame: P = 1216: 3.11 at 256 x 8, 2.24 at 512 x 4, 1.98 at 1024 x 2; P = 448: 1.97 at
     // 256 x 4, 1.47 at 1024 x 1; P = 256: 2.13 at 64 x 4, 1.35 at 256 x 1).
     if (P <= 64) SR_LAUNCH(64, 1);
     if (P <= 256) SR_LAUNCH(256, 1);
@@ -407,7 +407,7 @@ hipError_t launch_decode_fast(const DecodeArgs& a, hipStream_t stream) {
     if (P <= 64) SR_LAUNCH(64, 1);
     if (P <= 256) SR_LAUNCH(64, 4);
     if (P <= 1024) SR_LAUNCH(256, 4);
-    if (P <= 2048) SR_LAUNCH(512, 4);  // 1000 utterances at P = 1152: 8.31 ms per step against 8.53 (256 x 8) and 9.08 (1024 x 2)
+    if (P <= 2048) SR_LAUNCH(512, 4);  // 1000 utterances at P = 1216: 8.31 ms per step against 8.53 (256 x 8) and 9.08 (1024 x 2)
   }
   if (P <= 4096) SR_LAUNCH(1024, 4);  // measured 7.5 ms vs 8.4 ms for 512 x 8 on 1000 utterances of P = 4000
   if (P <= 8192) SR_LAUNCH(1024, 8);
