@@ -135,11 +135,12 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
   const double tl = a.net.tdp_loop, tf = a.net.tdp_forward, ts = a.net.tdp_skip;
   const double wp_word = a.word_penalty, thr = a.am_threshold;
 
-  // Slot of (thread, i).  Many utterances in flight (throughput): a wave owns SPT consecutive 64-slot chunks, so only the
-  // waves that hold word-end kinds pay for the word-end reduction.  Few utterances (latency): chunks are dealt round-robin
-  // so that every wave carries the same mix of kinds and none of them is the straggler at the frame barrier.
-  const bool dealt = a.n_utts < 128;
-  auto slot_of = [&](int i) -> uint32_t { return dealt ? tid + (uint32_t)i * NT : (wave * SPT + (uint32_t)i) * 64 + lane; };
+  // Slot of (thread, i): a wave owns SPT consecutive 64-slot chunks of the type-sorted net, so most waves hold one kind (the
+  // straight-line path below) and only the waves that hold word-end kinds pay for the word-end reduction.  (Round 1 dealt the
+  // chunks round-robin when few utterances were in flight, so that every wave carried the same mix of kinds; with the
+  // straight-line path the consecutive deal is faster there too: 2.04 -> 1.87 us per frame for one utterance of configs[1],
+  // 1.68 -> 1.49 ms for 64 utterances of configs[2].)
+  auto slot_of = [&](int i) -> uint32_t { return (wave * SPT + (uint32_t)i) * 64 + lane; };
   // ---- static per-slot constants ------------------------------------------------------------------------
   uint32_t st[SPT], pr[SPT], og[SPT], ty[SPT];
 #pragma unroll
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
       }
     };
     if (uniform_kind) {
-      // All SPT chunks of this wave are of one kind (the throughput layout deals consecutive chunks of the type-sorted net):
+      // All SPT chunks of this wave are of one kind (a wave holds consecutive chunks of the type-sorted net):
       // one scalar branch, then the SPT slots as straight-line code whose LDS reads and FP64 chains interleave -- per slot
       // the loop is a dependent chain, and four waves per SIMD do not hide it
 #pragma unroll
