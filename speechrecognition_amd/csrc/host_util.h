@@ -2,10 +2,13 @@
 #pragma once
 #include <stdint.h>
 
+#include <algorithm>
 #include <exception>
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 #include "../../include/srgpu.h"
@@ -48,6 +51,24 @@ int guarded(const char* entry, F&& body) noexcept {
   } catch (...) {
     return set_error(SR_EINTERNAL, (std::string(entry) + ": unexpected exception").c_str());
   }
+}
+
+// fn(i0, i1) over [0, n) on up to 16 host threads (one call on the caller's thread when n is small or threads are refused)
+template <typename F>
+inline void parallel_ranges(size_t n, size_t min_per_thread, F&& fn) {
+  const unsigned hw = std::thread::hardware_concurrency();
+  size_t nt = std::min<size_t>(16, hw ? hw : 1);
+  if (min_per_thread) nt = std::min(nt, n / min_per_thread);
+  if (nt <= 1) { fn((size_t)0, n); return; }
+  std::vector<std::thread> pool;
+  pool.reserve(nt);
+  size_t started = 0;
+  try {
+    for (; started + 1 < nt; started++) pool.emplace_back(fn, n * started / nt, n * (started + 1) / nt);
+  } catch (const std::system_error&) {  // a refused thread: its range and the rest run here
+  }
+  fn(n * started / nt, n);
+  for (auto& th : pool) th.join();
 }
 
 }  // namespace srhost

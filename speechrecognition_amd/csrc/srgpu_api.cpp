@@ -14,6 +14,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -160,9 +161,15 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
   {
     const uint32_t NS = (uint32_t)gmm_refine_slots(std::min(32u, m->max_dens)), planes = 2 * D + 2;
     m->pf_slots = NS;
-    std::vector<double> rows((size_t)PS * planes * NS + 128, 0.0);
-    for (uint32_t ps = 0; ps < PS; ps++) {
-      double* r = rows.data() + (size_t)ps * planes * NS;
+    // (the packings are built on first use of their kernel: on 16 host threads, a new model's first prefilter call was 170 ms)
+    const size_t n_rows_d = (size_t)PS * planes * NS + 128;
+    std::unique_ptr<double[]> rows_own(new double[n_rows_d]);
+    double* const rows_p = rows_own.get();
+    std::fill(rows_p + (size_t)PS * planes * NS, rows_p + n_rows_d, 0.0);
+    srhost::parallel_ranges(PS, 64, [&](size_t ps0, size_t ps1) {
+    for (uint32_t ps = (uint32_t)ps0; ps < (uint32_t)ps1; ps++) {
+      double* r = rows_p + (size_t)ps * planes * NS;
+      std::fill(r, r + (size_t)planes * NS, 0.0);
       for (uint32_t i = 0; i < ps_count(ps); i++) {
         const size_t c = (size_t)dens_off[ps / Cs] + 32u * (ps % Cs) + i;
         // density i sits in slot (i + ps) mod NS: the workgroup's 8 states are rotated against each other, so that
@@ -173,7 +180,8 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
         r[(2 * D + 1) * NS + sl] = logw[c];
       }
     }
-    HIP_TRY(m->pf_rows.upload(rows.data(), rows.size()));
+    });
+    HIP_TRY(m->pf_rows.upload(rows_p, n_rows_d));
   }
   const int KS = (int)((2 * D + 3 + 31) / 32);
   const uint32_t n_groups = (PS + 3) / 4;
@@ -189,17 +197,23 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
     }
     return norm[c] - logw[c] + 0.5 * q2;
   };
-  std::vector<double> arow(32 * (size_t)KS);
   // one power-of-two scale for the whole model, the largest finite |coefficient| or |constant| -> [2^13, 2^14)
   double sA = 1.0;
   {
+    std::mutex mu_big;
     double big = 0.0;
-    for (size_t c = 0; c < (size_t)m->n_dens; c++) {
-      const double konst = coeffs(c, arow);
-      if (std::isfinite(konst)) big = std::max(big, std::fabs(konst));
-      for (uint32_t k = 0; k < 2 * D; k++)
-        if (std::isfinite(arow[k])) big = std::max(big, std::fabs(arow[k]));
-    }
+    srhost::parallel_ranges((size_t)m->n_dens, 4096, [&](size_t c0, size_t c1) {
+      std::vector<double> arow(32 * (size_t)KS);
+      double mine = 0.0;
+      for (size_t c = c0; c < c1; c++) {
+        const double konst = coeffs(c, arow);
+        if (std::isfinite(konst)) mine = std::max(mine, std::fabs(konst));
+        for (uint32_t k = 0; k < 2 * D; k++)
+          if (std::isfinite(arow[k])) mine = std::max(mine, std::fabs(arow[k]));
+      }
+      std::lock_guard<std::mutex> lock(mu_big);
+      big = std::max(big, mine);
+    });
     if (big > 0.0) sA = std::ldexp(1.0, 13 - std::ilogb(big));
   }
   const size_t blk_bytes = (size_t)KS * 1024;
@@ -207,7 +221,9 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
   std::vector<float> anorm(8 * (size_t)n_groups, 0.0f);  // (sA |a|, sA |konst|) per state slot
   auto half_bits = [](double v) { const _Float16 h = (_Float16)(float)v; uint16_t u; memcpy(&u, &h, 2); return u; };
   auto half_value = [](uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (double)(float)h; };
-  for (uint32_t q = 0; q < n_groups; q++) {
+  srhost::parallel_ranges(n_groups, 16, [&](size_t q0, size_t q1) {
+  std::vector<double> arow(32 * (size_t)KS);
+  for (uint32_t q = (uint32_t)q0; q < (uint32_t)q1; q++) {
     for (uint32_t j = 0; j < 8; j++) {
       const size_t b = (size_t)q * 8 + j;
       for (uint32_t r = 0; r < 16; r++) {
@@ -243,6 +259,7 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
       }
     }
   }
+  });
   if (Cs > 1) {  // the candidate test of every chunk uses the whole state's largest |a| and |konst|
     for (uint32_t st = 0; st < S; st++)
       for (int f = 0; f < 2; f++) {
