@@ -178,7 +178,7 @@ def main():
     # north_star's "MFMA utilisation on the GMM step": the headline path no longer executes the dense FP64 contraction, so the
     # dense FP64-MFMA kernel (same scores to 1e-9) is timed once beside it, outside the timed region, for that figure
     dense_mfma = None
-    if rank == 0 and args.kernel == "prefilter" and bg is None and not args.no_dense_mfma:
+    if rank == 0 and world == 1 and args.kernel == "prefilter" and bg is None and not args.no_dense_mfma:
         corpus.recognize(lexh, args.beam, wp, capi.GMM_MFMA)  # builds the packing
         model.profile(True)
         torch.cuda.synchronize()
