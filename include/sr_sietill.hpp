@@ -456,12 +456,16 @@ struct FeaturePostProcessor {
     const size_t nf = n_features_in_file, nt = n_features_total(), T = features.size() / nf;
     std::vector<float> seq(T * nt, 0.0f);
     for (size_t f = 0; f < T; f++) std::copy(features.begin() + f * nf, features.begin() + (f + 1) * nf, seq.begin() + f * nt);
+    // An utterance of at most deriv_step frames: the reference indexes frame max(t, deriv_step) >= T and frame
+    // T - 1 - deriv_step (size_t underflow) -- reads past its buffer, results undefined (found by tools/sanitize_host.py; the
+    // corpus has no such utterance).  Here both windows are clamped into [0, T - 1] instead; for T > deriv_step the indices
+    // below are exactly the reference's.
     for (size_t t = 0; t < T; t++) {  // first derivative, window clamped at the start (:322-328)
-      const size_t a = std::max(t, deriv_step);
-      for (size_t k = 0; k < n_features_first; k++) seq[t * nt + nf + k] = seq[a * nt + k] - seq[(a - deriv_step) * nt + k];
+      const size_t a = std::min(std::max(t, deriv_step), T - 1), b = a >= deriv_step ? a - deriv_step : 0;
+      for (size_t k = 0; k < n_features_first; k++) seq[t * nt + nf + k] = seq[a * nt + k] - seq[b * nt + k];
     }
     for (size_t t = 0; t < T; t++) {  // second derivative from the first, window clamped at the end (:329-335)
-      const size_t a = std::min(t, T - 1 - deriv_step) + deriv_step;
+      const size_t a = T > deriv_step ? std::min(t, T - 1 - deriv_step) + deriv_step : T - 1;
       for (size_t k = 0; k < n_features_second; k++) seq[t * nt + nf + n_features_first + k] = seq[a * nt + nf + k] - seq[t * nt + nf + k];
     }
     if (!mean.empty()) {

@@ -41,6 +41,8 @@ extern "C" {
 #define SR_ELIMIT (-4)   /* size outside what the kernels support (message says which) */
 #define SR_ENOMEM (-5)   /* host allocation failed (std::bad_alloc caught at the boundary) */
 #define SR_EINTERNAL (-6) /* any other C++ exception caught at the boundary (message carries what()) */
+#define SR_ECORRUPT (-7) /* a traceback that does not walk back to frame 0 (a back pointer that does not fall, a word outside the
+                           lexicon): no words are reported for the call */
 
 /* GMM scoring kernels (MixtureModel::score, Mixtures.cpp:737-744) */
 #define SR_GMM_MFMA 0   /* FP64 MFMA contraction + fused min / log-sum epilogue (default; ~1e-15 rel.) */
@@ -141,6 +143,15 @@ typedef struct {
 SR_API int sr_recognize_corpus(sr_model* m, sr_corpus* c, sr_lexicon* l, const sr_search_params* p,
                         uint32_t* out_words, uint64_t* out_word_off,
                         double* tb_score, uint16_t* tb_word, uint16_t* tb_bkp);
+/* The traceback loop alone (Recognizer.cpp:222-231: `t = T; while (t > 0) { push word unless silence; t = traceback[t].bkp }`,
+ * reversed), with the checks every search kernel here applies before it follows an entry: bkp < t (the reference writes
+ * bkp = t - 1 of an earlier frame, :140,170, so t falls strictly), word < n_words, at most T words.  SR_ECORRUPT otherwise.
+ * sr_traceback_corpus walks caller-supplied dumps in sr_recognize_corpus' layout ([total_frames + n_utts], words not slots)
+ * on the device, with the kernels' own walker; sr_traceback_words walks one utterance's T + 1 entries on the host. */
+SR_API int sr_traceback_corpus(sr_model* m, sr_corpus* c, sr_lexicon* l, const uint16_t* tb_word, const uint16_t* tb_bkp,
+                               uint32_t* out_words, uint64_t* out_word_off);
+SR_API int sr_traceback_words(uint32_t n_frames, const uint16_t* tb_word, const uint16_t* tb_bkp, uint32_t silence_word,
+                              uint32_t n_words, uint32_t* out_words, uint32_t* out_count);
 /* one-shot convenience: upload + recognise + free */
 SR_API int sr_recognize_batch(sr_model* m, sr_lexicon* l, const sr_search_params* p, const float* feats,
                        const uint64_t* frame_off, uint32_t n_utts, uint32_t* out_words, uint64_t* out_word_off);

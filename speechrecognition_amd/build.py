@@ -20,8 +20,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsrgpu.so")
 SOURCES = ["srgpu_api.cpp", "mixset.cpp", "feeder.cpp", "gmm_mfma.hip", "gmm_exact.hip", "gmm_prefilter.hip", "viterbi_decode.hip",
            "viterbi_fast.hip", "viterbi_align.hip", "viterbi_bigram.hip", "em_accumulate.hip", "em_finalize.hip"]
-HEADERS = ["kernels.h", "host_util.h", "handles.h", os.path.join("..", "..", "include", "srgpu.h")]
-FLAGS = (["-DSR_DECODE_STAMPS"] if os.environ.get("SR_DECODE_STAMPS") else []) + ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+HEADERS = ["kernels.h", "host_util.h", "handles.h", "traceback.h", os.path.join("..", "..", "include", "srgpu.h")]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 # these replay the reference's SSE2 operation order and must not contract a*b+c into an FMA
 PER_FILE = {"gmm_exact.hip": ["-ffp-contract=off"], "gmm_prefilter.hip": ["-ffp-contract=off"], "em_accumulate.hip": ["-ffp-contract=off"],
             "em_finalize.hip": ["-ffp-contract=off"]}

@@ -18,12 +18,13 @@ LIB_PATH = os.environ.get("SRGPU_LIB") or os.path.join(HERE, "libsrgpu.so")
 GMM_MFMA, GMM_EXACT, GMM_PREFILTER = 0, 1, 2
 POOL_GLOBAL, POOL_MIXTURE, POOL_NONE = 0, 1, 2
 SEARCH_GENERAL_KERNEL = 1
+SR_ECORRUPT = -7
 
 # every symbol include/srgpu.h declares
 SYMBOLS = [
     "sr_last_error", "sr_device_count", "sr_model_create", "sr_model_load_mixset", "sr_model_destroy", "sr_model_info",
     "sr_corpus_upload", "sr_corpus_upload_async", "sr_corpus_wait", "sr_corpus_destroy", "sr_shard_utterances", "sr_recognize_batch_multi", "sr_score_corpus", "sr_score_frames", "sr_lexicon_create",
-    "sr_lexicon_destroy", "sr_recognize_corpus", "sr_recognize_batch", "sr_align_corpus", "sr_align_corpus_pruned", "sr_path_scores_corpus", "sr_model_create_from_statistics", "sr_model_create_from_accumulated", "sr_mixset_write", "sr_model_set_tying", "sr_model_tying_info", "sr_model_topology", "sr_accumulate_corpus",
+    "sr_lexicon_destroy", "sr_recognize_corpus", "sr_traceback_corpus", "sr_traceback_words", "sr_recognize_batch", "sr_align_corpus", "sr_align_corpus_pruned", "sr_path_scores_corpus", "sr_model_create_from_statistics", "sr_model_create_from_accumulated", "sr_mixset_write", "sr_model_set_tying", "sr_model_tying_info", "sr_model_topology", "sr_accumulate_corpus",
     "sr_bigram_create", "sr_bigram_destroy", "sr_recognize_bigram_corpus",
     "sr_probe_fp16_denormals", "sr_probe_fp16_accumulation",
     "sr_profile_enable", "sr_profile_reset", "sr_profile_read",
@@ -80,6 +81,8 @@ def lib():
         L.sr_lexicon_destroy.argtypes = [vp]
         L.sr_recognize_corpus.argtypes = [vp, vp, vp, C.POINTER(SearchParams), vp, vp, vp, vp, vp]
         L.sr_recognize_batch.argtypes = [vp, vp, C.POINTER(SearchParams), vp, vp, u32, vp, vp]
+        L.sr_traceback_corpus.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+        L.sr_traceback_words.argtypes = [u32, vp, vp, u32, u32, vp, C.POINTER(u32)]
         L.sr_align_corpus.argtypes = [vp, vp, vp, vp, C.POINTER(dbl * 3), C.c_uint16, i32, vp, vp]
         L.sr_align_corpus_pruned.argtypes = [vp, vp, vp, vp, C.POINTER(dbl * 3), C.c_uint16, dbl, i32, vp, vp]
         L.sr_path_scores_corpus.argtypes = [vp, vp, vp, i32, vp]
@@ -281,6 +284,16 @@ class Corpus:
             return words, woff, (tbs, tbw, tbb)
         return words, woff
 
+    def retrace(self, lexicon, tb_word, tb_bkp):
+        """sr_traceback_corpus: the device's traceback walk alone on dumps in recognize(traceback=True)'s layout."""
+        tb_word = np.ascontiguousarray(tb_word, dtype=np.uint16)
+        tb_bkp = np.ascontiguousarray(tb_bkp, dtype=np.uint16)
+        assert len(tb_word) == len(tb_bkp) == self.n_frames + self.n_utts
+        words = np.zeros(max(self.n_frames, 1), dtype=np.uint32)
+        woff = np.zeros(self.n_utts + 1, dtype=np.uint64)
+        _check(lib().sr_traceback_corpus(self.model.h, self.h, lexicon.h, _ptr(tb_word), _ptr(tb_bkp), _ptr(words), _ptr(woff)))
+        return words[: int(woff[-1])].copy(), woff
+
     def _aut(self, automata):
         flat = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.uint16) for a in automata]), dtype=np.uint16)
         off = np.concatenate([[0], np.cumsum([len(a) for a in automata])]).astype(np.uint64)
@@ -356,6 +369,17 @@ class Lexicon:
         if self.h:
             lib().sr_lexicon_destroy(self.h)
             self.h = None
+
+
+def traceback_words(tb_word, tb_bkp, silence_word, n_words):
+    """sr_traceback_words: Recognizer.cpp:222-231 on one utterance's traceback[0..T] (host side, guarded)."""
+    tb_word = np.ascontiguousarray(tb_word, dtype=np.uint16)
+    tb_bkp = np.ascontiguousarray(tb_bkp, dtype=np.uint16)
+    T = len(tb_word) - 1
+    out = np.zeros(max(T, 1), dtype=np.uint32)
+    n = C.c_uint32(0)
+    _check(lib().sr_traceback_words(T, _ptr(tb_word), _ptr(tb_bkp), silence_word, n_words, _ptr(out), C.byref(n)))
+    return out[: n.value].copy()
 
 
 def mixset_write(path, dim, dens_off, dens_mean, dens_var, acc):

@@ -168,7 +168,14 @@ __global__ __launch_bounds__(256) void em_sum_kernel(EmArgs a, const uint32_t* r
       if (i + 64 < e) meta(i + 64, pw_n, fr_n);  // the next batch's metadata travels while this batch is summed
       // this lane's pair to the wave's LDS slots: the loop below reads element j from ONE address (a broadcast read)
       // instead of three v_readlane + the offset multiplication per element
+      // (wave-scope release / acquire around the exchange: the slots are written by one lane each and read by all, and the
+      // next batch overwrites them -- without the fences only the in-order LDS pipe and the compiler's may-alias ordering
+      // kept that correct, and the bit-exact statistics depend on it; they cost nothing)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // every lane's reads of the previous batch come before ...
       slot[lane] = make_ulonglong2((unsigned long long)fr * D, (unsigned long long)__double_as_longlong(pw));
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // ... and every lane's store is visible to the reads below
       for (uint32_t j0 = 0; j0 < n; j0 += kF) {  // wave-uniform
         double yy[kF];
 #pragma unroll

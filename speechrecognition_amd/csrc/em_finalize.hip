@@ -162,11 +162,9 @@ static int finalize_core(int device, uint32_t dim, uint32_t n_states, const uint
   if (pooling == SRHOST_POOL_GLOBAL && n_var > 0) var_src[0] = 0;
   const unsigned hw = std::thread::hardware_concurrency();
   const size_t n_threads = C >= 4096 ? std::max(1u, std::min(16u, hw ? hw : 1u)) : 1;
-  auto spread = [&](size_t n, auto&& fn) {  // fn(i0, i1) over [0, n) on n_threads host threads
+  auto spread = [&](size_t n, auto&& fn) {  // fn(i0, i1) over [0, n) on n_threads host threads (joined and exception-safe: host_util.h)
     if (n_threads <= 1 || n < 1024) { fn((size_t)0, n); return; }
-    std::vector<std::thread> pool;
-    for (size_t t = 0; t < n_threads; t++) pool.emplace_back(fn, n * t / n_threads, n * (t + 1) / n_threads);
-    for (auto& th : pool) th.join();
+    srhost::parallel_ranges(n, 1, fn, n_threads);
   };
   // log weights per density: log(w / observations of the LAST mixture that references the mean row) (:401-405)
   spread(C, [&](size_t c0, size_t c1) {
@@ -254,9 +252,10 @@ static int finalize_core(int device, uint32_t dim, uint32_t n_states, const uint
     if (n_threads <= 1 || n_var < 1024) {
       rows(0, 1);
     } else {
-      std::vector<std::thread> pool;
-      for (size_t t = 0; t < n_threads; t++) pool.emplace_back(rows, t, n_threads);
-      for (auto& th : pool) th.join();
+      srhost::ThreadGroup pool(n_threads - 1);
+      for (size_t t = 0; t + 1 < n_threads; t++) pool.run([&rows, t, n_threads]() { rows(t, n_threads); });
+      pool.run_here([&]() { rows(n_threads - 1, n_threads); });
+      pool.wait();
     }
     if (pinned)
       for (int k = 0; k < kPieces; k++) (void)hipEventDestroy(ev[k]);

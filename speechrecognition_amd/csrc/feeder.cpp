@@ -193,11 +193,19 @@ int corpus_ready(sr_corpus* c, uint64_t f0, uint64_t f1, hipStream_t stream) {
   const uint64_t D = c->model->dim;
   const uint32_t p0 = (uint32_t)(f0 * D / fd->piece_floats);
   const uint32_t p1 = (uint32_t)std::min<uint64_t>(fd->n_pieces, (f1 * D + fd->piece_floats - 1) / fd->piece_floats);
+  bool landed;
   {
     std::unique_lock<std::mutex> lk(fd->mu);
     fd->cv.wait(lk, [&] { return fd->n_issued >= p1 || fd->rc != SR_OK; });
     if (fd->rc != SR_OK) return fail(fd->rc, "%s", fd->err.c_str());
-    if (fd->finished) return SR_OK;  // everything has landed (the feeder synchronised its stream)
+    landed = fd->finished;
+  }
+  if (landed) {
+    // Everything has landed (the feeder synchronised its stream): hand the model's copy stream, pinned buffers and the piece
+    // events back NOW, not at sr_corpus_destroy -- a corpus that stays resident (a training iteration, a bench loop) would
+    // otherwise keep the lease and every later sr_recognize_batch on the model would allocate its own.
+    feeder_join(c);
+    return SR_OK;
   }
   // copies on s_copy complete in order: the last piece of the range covers the earlier ones
   if (p1 > p0) {
@@ -233,9 +241,12 @@ int sr_corpus_wait(sr_corpus* c) {
     if (!c) return fail(SR_EINVAL, "null corpus handle");
     sr_feeder* fd = c->feeder;
     if (!fd) return SR_OK;
-    std::unique_lock<std::mutex> lk(fd->mu);
-    fd->cv.wait(lk, [&] { return fd->finished; });
-    if (fd->rc != SR_OK) return fail(fd->rc, "%s", fd->err.c_str());
+    {
+      std::unique_lock<std::mutex> lk(fd->mu);
+      fd->cv.wait(lk, [&] { return fd->finished; });
+      if (fd->rc != SR_OK) return fail(fd->rc, "%s", fd->err.c_str());  // (the feeder stays: later calls report the same error)
+    }
+    srhost::feeder_join(c);  // joins the thread, destroys the piece events and returns the model's staging lease
     return SR_OK;
   });
 }
@@ -317,10 +328,12 @@ int sr_recognize_batch_multi(sr_model* const* models, sr_lexicon* const* lexica,
         sh.rc = SR_EINTERNAL; sh.err = "unexpected exception in a device thread";
       }
     };
-    std::vector<std::thread> pool;
-    for (uint32_t d = 1; d < n_devices; d++) pool.emplace_back(work, d);
-    work(0);  // the caller's thread drives the first device
-    for (std::thread& t : pool) t.join();
+    {
+      srhost::ThreadGroup pool(n_devices - 1);  // joins in its destructor; a refused thread's device is driven from this thread
+      for (uint32_t d = 1; d < n_devices; d++) pool.run([&work, d]() { work(d); });
+      pool.run_here([&work]() { work(0); });  // the caller's thread drives the first device
+      pool.wait();
+    }
     for (uint32_t d = 0; d < n_devices; d++)
       if (shards[d].rc != SR_OK) return fail(shards[d].rc, "device slot %u (device %d): %s", d, models[d]->device, shards[d].err.c_str());
     // gather in corpus order

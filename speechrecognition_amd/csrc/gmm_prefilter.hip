@@ -416,10 +416,6 @@ int gmm_prefilter_frames_per_tile() { return kPWaves * SR_P16_NB * 16; }
 static constexpr int kRThreads = SR_R_THREADS;   // 3 waves per SIMD; the register budget of 168 holds x in FP64 (78) + pipeline
 static constexpr int kRWaves = kRThreads / 64;
 static constexpr int kRBatch = SR_R_BATCH;       // dimensions per software-pipeline stage of the candidate evaluation
-#ifndef SR_R_EXP
-#define SR_R_EXP 0   // timing experiments only (tools/build_variant.py, profiles/r2_refine_decomposition.txt): 2 = main pass + list appends, 1 = main pass
-                     // alone (wrong scores), 5 = main pass without its LDS reads, 6 = main pass without its arithmetic
-#endif
 static constexpr uint32_t kRingEntries = 128;    // per (wave, level, state): < 64 pending + <= 64 appended per iteration
 static constexpr uint32_t kRingLists = 2 * 8 * kRingEntries;  // entries per wave: [level][state][128]
 static constexpr uint32_t kRingWave = 4 * kRingLists;         // u32 per wave: 16-byte entries
@@ -506,10 +502,7 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
       double pm[2][kRBatch], pv[2][kRBatch];
 #pragma unroll
       for (int i = 0; i < kRBatch; i++)
-        if (i <= DT) {
-          if (SR_R_EXP == 5) { pm[0][i] = x[DT ? (i + 1) % DT : 0]; pv[0][i] = x[DT ? (i + 2) % DT : 0]; }
-          else { pm[0][i] = col[(2 * i) * NS]; pv[0][i] = col[(2 * i + 1) * NS]; }
-        }
+        if (i <= DT) { pm[0][i] = col[(2 * i) * NS]; pv[0][i] = col[(2 * i + 1) * NS]; }
 #pragma unroll
       for (int b = 0; b < NB_; b++) {
         const int cur = b & 1;
@@ -517,16 +510,12 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
 #pragma unroll
         for (int i = 0; i < kRBatch; i++) {
           const int k = (b + 1) * kRBatch + i;
-          if (k <= DT) {
-            if (SR_R_EXP == 5) { pm[cur ^ 1][i] = x[DT ? (k + 1) % DT : 0]; pv[cur ^ 1][i] = x[DT ? (k + 2) % DT : 0]; }
-            else { pm[cur ^ 1][i] = col[(2 * k) * NS]; pv[cur ^ 1][i] = col[(2 * k + 1) * NS]; }
-          }
+          if (k <= DT) { pm[cur ^ 1][i] = col[(2 * k) * NS]; pv[cur ^ 1][i] = col[(2 * k + 1) * NS]; }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < kRBatch; i++) {
           const int k = b * kRBatch + i;
-          if (SR_R_EXP == 6) { asm volatile("" :: "v"(pm[cur][i]), "v"(pv[cur][i])); if (k == DT) score = pm[cur][i]; continue; }
           if (k < (int)(DT - (DT & 1))) {
             double u = x[DT ? k : 0] - pm[cur][i];
             u = u * u;
@@ -604,7 +593,7 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
           if (counting) n_eval += (valid && mask != 0) ? 1u : 0u;
         }
         const bool more = valid && (mask & (mask - 1)) != 0;
-        const uint64_t b = (SR_R_EXP == 1 || SR_R_EXP >= 5) ? 0 : __ballot(more);
+        const uint64_t b = __ballot(more);
         if (b) {  // wave-uniform
           const uint32_t c1 = (uint32_t)(cnt1 >> (8 * j)) & 0xFFu;
           const uint32_t pos = c1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
@@ -653,7 +642,6 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
     // table stores issued after the last list store (wave-uniform): SPW/2 row pieces, unless the data-dependent paths ran
     uint32_t tail_stores = (!chunk_shift && ns == SPW && __any(valid)) ? (uint32_t)(SPW / 2) : 0u;
     for (;;) {
-      if (SR_R_EXP == 2) { cnt1 &= 0x3F3F3F3F3F3F3F3Full; break; }  // main pass + appends, lists never worked off
       uint32_t level, j, n;
       {
         const uint64_t full1 = cnt1 & 0x4040404040404040ull, full2 = cnt2 & 0x4040404040404040ull;

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <exception>
+#include <mutex>
 #include <new>
 #include <stdexcept>
 #include <string>
@@ -53,22 +54,74 @@ int guarded(const char* entry, F&& body) noexcept {
   }
 }
 
-// fn(i0, i1) over [0, n) on up to 16 host threads (one call on the caller's thread when n is small or threads are refused)
+// Worker threads that cannot outlive their scope and cannot take the process down: the destructor joins (a joinable
+// std::thread that is destroyed calls std::terminate -- what an exception thrown between emplace_back and join used to do),
+// a worker's exception is kept and rethrown by wait() on the caller's thread (where `guarded` turns it into an SR_E* code),
+// and a thread the system refuses (std::system_error) runs its work on the calling thread instead.
+class ThreadGroup {
+ public:
+  explicit ThreadGroup(size_t expected) { pool_.reserve(expected); }  // (no reallocation while threads exist)
+  ThreadGroup(const ThreadGroup&) = delete;
+  ThreadGroup& operator=(const ThreadGroup&) = delete;
+  ~ThreadGroup() { join_all(); }
+  template <typename F>
+  void run(F fn) {
+    auto body = [this, fn]() mutable {
+      try {
+        fn();
+      } catch (...) {
+        std::lock_guard<std::mutex> g(mu_);
+        if (!first_) first_ = std::current_exception();
+      }
+    };
+    if (pool_.size() < pool_.capacity()) {
+      try {
+        pool_.emplace_back(body);
+        return;
+      } catch (const std::system_error&) {  // refused: below, on this thread
+      }
+    }
+    body();
+  }
+  // the calling thread's own share: exceptions are kept like a worker's, so that wait() reports the first of all
+  template <typename F>
+  void run_here(F fn) {
+    try {
+      fn();
+    } catch (...) {
+      std::lock_guard<std::mutex> g(mu_);
+      if (!first_) first_ = std::current_exception();
+    }
+  }
+  void wait() {
+    join_all();
+    if (first_) { std::exception_ptr e = first_; first_ = nullptr; std::rethrow_exception(e); }
+  }
+
+ private:
+  void join_all() noexcept {
+    for (std::thread& t : pool_)
+      if (t.joinable()) t.join();
+  }
+  std::vector<std::thread> pool_;
+  std::mutex mu_;
+  std::exception_ptr first_;
+};
+
+// fn(i0, i1) over [0, n) on up to `max_threads` (default 16) host threads; one call on the caller's thread when n is small
 template <typename F>
-inline void parallel_ranges(size_t n, size_t min_per_thread, F&& fn) {
+inline void parallel_ranges(size_t n, size_t min_per_thread, F&& fn, size_t max_threads = 16) {
   const unsigned hw = std::thread::hardware_concurrency();
-  size_t nt = std::min<size_t>(16, hw ? hw : 1);
+  size_t nt = std::min<size_t>(max_threads, hw ? hw : 1);
   if (min_per_thread) nt = std::min(nt, n / min_per_thread);
   if (nt <= 1) { fn((size_t)0, n); return; }
-  std::vector<std::thread> pool;
-  pool.reserve(nt);
-  size_t started = 0;
-  try {
-    for (; started + 1 < nt; started++) pool.emplace_back(fn, n * started / nt, n * (started + 1) / nt);
-  } catch (const std::system_error&) {  // a refused thread: its range and the rest run here
+  ThreadGroup g(nt - 1);
+  for (size_t t = 0; t + 1 < nt; t++) {
+    const size_t a = n * t / nt, b = n * (t + 1) / nt;
+    g.run([&fn, a, b]() { fn(a, b); });
   }
-  fn(n * started / nt, n);
-  for (auto& th : pool) th.join();
+  g.run_here([&]() { fn(n * (nt - 1) / nt, n); });
+  g.wait();
 }
 
 }  // namespace srhost

@@ -133,7 +133,7 @@ struct DecodeArgs {
   uint16_t* tb_bkp;
   uint32_t* out_words;          // utterance u writes its words at out_words[frame_off[u] ...]
   uint32_t* out_count;          // [n_utts_total]
-  uint32_t* out_flags;          // [n_utts_total] bit0: slow (sequential-emulation) path was taken
+  uint32_t* out_flags;          // [n_utts_total] kFlagSlowPath | kFlagReplay | kFlagCorrupt (traceback.h)
   uint32_t force_general;       // skip the fast kernel: every utterance goes through decode_kernel<.., REPLAY = true>
 };
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream);       // fast variant, then the replay variant for flagged utterances
@@ -143,6 +143,10 @@ uint32_t decode_max_slots();          // what the LDS-resident kernels hold
 uint32_t decode_big_max_slots();
 size_t decode_big_workspace(uint32_t n_slots);
 hipError_t launch_decode_big(const DecodeArgs& a, unsigned char* ws, hipStream_t stream);
+// the traceback walk alone (traceback.h) on arrays in the traceback layout above; out_flags[u] = kFlagCorrupt where it does not walk
+hipError_t launch_traceback(const uint64_t* frame_off, uint32_t n_utts, const uint16_t* tb_word, const uint16_t* tb_bkp,
+                            uint32_t silence_word, uint32_t n_words, uint32_t* out_words, uint32_t* out_count,
+                            uint32_t* out_flags, hipStream_t stream);
 
 // ---- forced aligners (viterbi_align.hip) ----------------------------------------------------------
 struct AlignArgs {

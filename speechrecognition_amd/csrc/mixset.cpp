@@ -187,13 +187,10 @@ static void finalize_mixset(const Mixset& ms, int pooling, MixsetTables* out) {
   const unsigned hw = std::thread::hardware_concurrency();
   const size_t n_threads = (independent && mixtures.size() >= 256) ? std::max(1u, std::min(16u, hw ? hw : 1u)) : 1;
   if (n_threads > 1) {
-    std::vector<std::thread> pool;
-    for (size_t t = 0; t < n_threads; t++)
-      pool.emplace_back([&, t]() {
-        std::vector<double> pooled(D);
-        for (size_t mi = mixtures.size() * t / n_threads; mi < mixtures.size() * (t + 1) / n_threads; mi++) do_mixture(mi, pooled);
-      });
-    for (auto& th : pool) th.join();
+    parallel_ranges(mixtures.size(), 1, [&](size_t m0, size_t m1) {  // (joined and exception-safe: host_util.h)
+      std::vector<double> pooled(D);
+      for (size_t mi = m0; mi < m1; mi++) do_mixture(mi, pooled);
+    }, n_threads);
   } else {
     std::vector<double> pooled(D);
     for (size_t mi = 0; mi < mixtures.size(); mi++) do_mixture(mi, pooled);

@@ -22,6 +22,7 @@
 #include "../../include/srgpu.h"
 #include "host_util.h"
 #include "kernels.h"
+#include "traceback.h"
 
 using namespace srgpu;
 using srhost::guarded;
@@ -283,18 +284,18 @@ int set_prefilter_splits(sr_model* m, uint32_t nx) {
   const uint32_t target_wgs = 16 * 768;
   uint32_t ny = (target_wgs + nx - 1) / std::max(1u, nx);
   ny = std::max(1u, std::min(ny, std::max(1u, m->pf_groups / 8)));
-  if (const char* e = getenv("SRGPU_PF_NY")) ny = std::max(1u, std::min((uint32_t)atoi(e), m->pf_groups));
   if (ny >= 8) ny &= ~7u;
   // one table per split count, kept: launches of different sizes (the pieces of a corpus that is still being fed) alternate
   // between them without touching a table a queued kernel may still read
-  std::unique_ptr<DevBuf<uint32_t>>& tab = m->pf_split_tabs[ny];
-  if (!tab) {
+  auto it = m->pf_split_tabs.find(ny);
+  if (it == m->pf_split_tabs.end() || !it->second || !it->second->p) {
     std::vector<uint32_t> sb(ny + 1);
     for (uint32_t y = 0; y <= ny; y++) sb[y] = (uint32_t)((uint64_t)m->pf_groups * y / ny);
-    tab.reset(new DevBuf<uint32_t>());
-    HIP_TRY(tab->upload(sb.data(), sb.size()));
+    std::unique_ptr<DevBuf<uint32_t>> fresh(new DevBuf<uint32_t>());
+    HIP_TRY(fresh->upload(sb.data(), sb.size()));  // (a failed upload leaves no entry behind: the next call tries again)
+    it = m->pf_split_tabs.insert_or_assign(ny, std::move(fresh)).first;
   }
-  m->pf_split_cur = tab->p;
+  m->pf_split_cur = it->second->p;
   m->pf_ny = ny;
   return SR_OK;
 }
@@ -308,8 +309,8 @@ int set_splits(sr_model* m, uint32_t nx) {
   uint32_t ny = (target_wgs + nx - 1) / std::max(1u, nx);
   ny = std::max(1u, std::min(ny, std::min(m->n_groups, std::max(1u, m->n_blocks / 32))));
   if (ny >= 8) ny &= ~7u;  // multiples of 8 enable the XCD-aware tile map
-  std::unique_ptr<DevBuf<uint32_t>>& tab = m->split_tabs[ny];  // (kept per split count, see set_prefilter_splits)
-  if (!tab) {
+  auto it = m->split_tabs.find(ny);  // (kept per split count, see set_prefilter_splits)
+  if (it == m->split_tabs.end() || !it->second || !it->second->p) {
     std::vector<uint32_t> sb(ny + 1);
     for (uint32_t y = 0; y <= ny; y++) {
       // balance by blocks, cut at group boundaries
@@ -319,10 +320,11 @@ int set_splits(sr_model* m, uint32_t nx) {
     }
     sb[0] = 0;
     sb[ny] = m->n_blocks;
-    tab.reset(new DevBuf<uint32_t>());
-    HIP_TRY(tab->upload(sb.data(), sb.size()));
+    std::unique_ptr<DevBuf<uint32_t>> fresh(new DevBuf<uint32_t>());
+    HIP_TRY(fresh->upload(sb.data(), sb.size()));
+    it = m->split_tabs.insert_or_assign(ny, std::move(fresh)).first;
   }
-  m->split_cur = tab->p;
+  m->split_cur = it->second->p;
   m->split_ny = ny;
   return SR_OK;
 }
@@ -871,6 +873,27 @@ int sr_lexicon_destroy(sr_lexicon* l) {
   });
 }
 
+// Words of utterance u start at out_words[frame_off[u]] on the device, out_count[u] of them; a kernel that could not walk an
+// utterance's traceback (traceback.h) has raised kFlagCorrupt instead of reporting words: SR_ECORRUPT, naming the first one.
+static int gather_words(sr_corpus* c, uint32_t* out_words, uint64_t* out_word_off) {
+  const uint32_t U = c->n_utts;
+  const uint64_t F = c->n_frames;
+  std::vector<uint32_t> counts(U), flags(U), dev_words(F);
+  if (U) HIP_TRY(hipMemcpy(counts.data(), c->out_count.p, sizeof(uint32_t) * U, hipMemcpyDeviceToHost));
+  if (U) HIP_TRY(hipMemcpy(flags.data(), c->out_flags.p, sizeof(uint32_t) * U, hipMemcpyDeviceToHost));
+  if (F) HIP_TRY(hipMemcpy(dev_words.data(), c->out_words.p, sizeof(uint32_t) * F, hipMemcpyDeviceToHost));
+  uint64_t w = 0;
+  out_word_off[0] = 0;
+  for (uint32_t u = 0; u < U; u++) {
+    if (flags[u] & kFlagCorrupt) return fail(SR_ECORRUPT, "utterance %u: the traceback does not walk back to frame 0 (Recognizer.cpp:222-231)", u);
+    const uint64_t b = c->frame_off[u], T = c->frame_off[u + 1] - b;
+    if (counts[u] > T) return fail(SR_ECORRUPT, "utterance %u: %u words for %llu frames", u, counts[u], (unsigned long long)T);
+    for (uint32_t i = 0; i < counts[u]; i++) out_words[w++] = dev_words[b + i];
+    out_word_off[u + 1] = w;
+  }
+  return SR_OK;
+}
+
 int sr_recognize_corpus(sr_model* m, sr_corpus* c, sr_lexicon* l, const sr_search_params* p, uint32_t* out_words,
                         uint64_t* out_word_off, double* tb_score, uint16_t* tb_word, uint16_t* tb_bkp) {
   return guarded(__func__, [&]() -> int {
@@ -931,21 +954,49 @@ int sr_recognize_corpus(sr_model* m, sr_corpus* c, sr_lexicon* l, const sr_searc
   HIP_TRY(hipStreamSynchronize(m->s_search));
   HIP_TRY(hipStreamSynchronize(m->s_gmm));
 
-  // gather results: words of utterance u start at out_words[frame_off[u]] on the device
-  std::vector<uint32_t> counts(U), dev_words(F);
-  if (U) HIP_TRY(hipMemcpy(counts.data(), c->out_count.p, sizeof(uint32_t) * U, hipMemcpyDeviceToHost));
-  if (F) HIP_TRY(hipMemcpy(dev_words.data(), c->out_words.p, sizeof(uint32_t) * F, hipMemcpyDeviceToHost));
-  uint64_t w = 0;
-  out_word_off[0] = 0;
-  for (uint32_t u = 0; u < U; u++) {
-    const uint64_t b = c->frame_off[u];
-    for (uint32_t i = 0; i < counts[u]; i++) out_words[w++] = dev_words[b + i];
-    out_word_off[u + 1] = w;
-  }
+  if ((rc = gather_words(c, out_words, out_word_off))) return rc;
   if (tb_score) HIP_TRY(hipMemcpy(tb_score, c->tb_score.p, sizeof(double) * (F + U), hipMemcpyDeviceToHost));
   if (tb_word) HIP_TRY(hipMemcpy(tb_word, c->tb_word.p, sizeof(uint16_t) * (F + U), hipMemcpyDeviceToHost));
   if (tb_bkp) HIP_TRY(hipMemcpy(tb_bkp, c->tb_bkp.p, sizeof(uint16_t) * (F + U), hipMemcpyDeviceToHost));
   if (m->profiling) m->prof.frames += F;
+  return SR_OK;
+  });
+}
+
+int sr_traceback_corpus(sr_model* m, sr_corpus* c, sr_lexicon* l, const uint16_t* tb_word, const uint16_t* tb_bkp,
+                        uint32_t* out_words, uint64_t* out_word_off) {
+  return guarded(__func__, [&]() -> int {
+  int rc = check_model(m);
+  if (rc) return rc;
+  if (!c || c->model != m) return fail(SR_EINVAL, "corpus does not belong to this model");
+  if (!l || l->model != m) return fail(SR_EINVAL, "lexicon does not belong to this model");
+  if (!tb_word || !tb_bkp || !out_word_off || (!out_words && c->n_frames)) return fail(SR_EINVAL, "null argument");
+  const uint32_t U = c->n_utts;
+  const uint64_t F = c->n_frames;
+  HIP_TRY(c->tb_word.ensure(F + U));
+  HIP_TRY(c->tb_bkp.ensure(F + U));
+  HIP_TRY(c->out_words.ensure(F));
+  HIP_TRY(c->out_count.ensure(U));
+  HIP_TRY(c->out_flags.ensure(U));
+  HIP_TRY(hipMemcpyAsync(c->tb_word.p, tb_word, sizeof(uint16_t) * (F + U), hipMemcpyHostToDevice, m->s_gmm));
+  HIP_TRY(hipMemcpyAsync(c->tb_bkp.p, tb_bkp, sizeof(uint16_t) * (F + U), hipMemcpyHostToDevice, m->s_gmm));
+  HIP_TRY(launch_traceback(c->d_frame_off.p, U, c->tb_word.p, c->tb_bkp.p, l->silence_idx, l->n_words, c->out_words.p,
+                           c->out_count.p, c->out_flags.p, m->s_gmm));
+  HIP_TRY(hipStreamSynchronize(m->s_gmm));
+  return gather_words(c, out_words, out_word_off);
+  });
+}
+
+int sr_traceback_words(uint32_t n_frames, const uint16_t* tb_word, const uint16_t* tb_bkp, uint32_t silence_word, uint32_t n_words,
+                       uint32_t* out_words, uint32_t* out_count) {
+  return guarded(__func__, [&]() -> int {
+  if (!tb_word || !tb_bkp || !out_count || (!out_words && n_frames)) return fail(SR_EINVAL, "null argument");
+  *out_count = 0;
+  const uint32_t n = walk_traceback(
+      n_frames, silence_word, n_words, [&](uint32_t t) -> uint32_t { return tb_word[t]; },
+      [&](uint32_t t) -> uint32_t { return tb_bkp[t]; }, out_words, n_frames);
+  if (n == kTbCorrupt) return fail(SR_ECORRUPT, "not a traceback: a back pointer that does not fall, or a word outside the lexicon");
+  *out_count = n;
   return SR_OK;
   });
 }

@@ -32,6 +32,7 @@
 #include <stdlib.h>
 
 #include "kernels.h"
+#include "traceback.h"
 
 namespace srgpu {
 
@@ -45,22 +46,6 @@ static constexpr uint32_t kSlotFirstSil = 1u << 21;  // word's first state is th
 static constexpr uint32_t kSlotSingle = 1u << 22;    // one-position word: owns the virtual dead slot (w, 1)
 
 static constexpr double kInf = __builtin_huge_val();
-
-// Diagnostic build only (-DSR_DECODE_STAMPS): per-phase cycle sums of wave 0, written over traceback
-// scores 1..6 of the utterance at the end.  Never defined in the shipped library.
-#ifdef SR_DECODE_STAMPS
-#define SR_STAMP(k)                                                                     \
-  do {                                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                  \
-    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                       \
-    __builtin_amdgcn_s_waitcnt(0xC07F);                                                 \
-    stamp_sum[k] += now_ - stamp_last;                                                  \
-    stamp_last = now_;                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                  \
-  } while (0)
-#else
-#define SR_STAMP(k) do {} while (0)
-#endif
 
 struct Merge {  // one target hypothesis being built (Book, Recognizer.hpp:75-89; word/pos are static)
   double score;
@@ -144,7 +129,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeArgs a) {
   uint16_t* bk = reinterpret_cast<uint16_t*>(e_first + 12);         // [PP] back pointers (start frame of the word)
 
   const uint32_t u = a.utt_order ? a.utt_order[a.utt_first + blockIdx.x] : a.utt_first + blockIdx.x;
-  if (REPLAY && !a.force_general && !(a.out_flags[u] & 2u)) return;  // wave-uniform: nothing to redo for this utterance
+  if (REPLAY && !a.force_general && !(a.out_flags[u] & kFlagReplay)) return;  // wave-uniform: nothing to redo for this utterance
   const uint64_t f0 = a.frame_off[u];
   const uint32_t T = (uint32_t)(a.frame_off[u + 1] - f0);
   const double* row0 = a.scores + (f0 - a.frame_base) * a.ld;
@@ -185,9 +170,6 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeArgs a) {
   }
   __syncthreads();
   uint32_t slow_taken = 0;
-#ifdef SR_DECODE_STAMPS
-  unsigned long long stamp_sum[6] = {0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
-#endif
 
   // one frame; returns true when the fast variant has to hand the utterance to the replay variant
   auto frame = [&](const uint32_t t, double (&am_issue)[SPT], double (&am_consume)[SPT]) -> bool {
@@ -200,7 +182,6 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeArgs a) {
       for (int i = 0; i < SPT; i++) am_issue[i] = rown[info[i] & 0xFFFFu];
     }
 
-    SR_STAMP(0);  // loop overhead + gather issue
     // ---- A: build the new hypotheses in registers ------------------------------------------------
     // Branch-free: every slot makes the same five offers in ascending source order -- [boundary], skip,
     // forward, loop, [boundary] -- where a candidate that does not exist for this slot is +inf, which
@@ -295,16 +276,13 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeArgs a) {
     }
     if (tid < 4) ef_nxt[tid] = 0xFFFFFFFFu;
 
-    SR_STAMP(1);  // phase A
     // ---- B: block reductions -----------------------------------------------------------------------
     my_best = wave_min(my_best);
     wave_min_idx(my_we, my_we_idx);
     if (lane == 0) { red_best[wave] = my_best; red_we[wave] = my_we; red_idx[wave] = my_we_idx; }
-    SR_STAMP(2);  // wave reductions
     __syncthreads();  // also: every read of sc/bk of frame t-1 is done
-    SR_STAMP(3);  // barrier 1
     if (!REPLAY && *bail) {  // workgroup-uniform
-      if (tid == 0) { atomicOr(&a.out_flags[u], 2u); a.out_count[u] = 0; }
+      if (tid == 0) { atomicOr(&a.out_flags[u], kFlagReplay); a.out_count[u] = 0; }
       return true;
     }
     double best = red_best[0], we = red_we[0];
@@ -345,9 +323,7 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeArgs a) {
       }
     }
     if (!we_alive && tid == 0) { a.tb_score[tb0 + t] = kInf; a.tb_word[tb0 + t] = 0xFFFFu; a.tb_bkp[tb0 + t] = 0; }
-    SR_STAMP(4);  // partial combine + phase C
     __syncthreads();
-    SR_STAMP(5);  // barrier 2
     return false;
   };
 
@@ -360,28 +336,26 @@ __global__ __launch_bounds__(NT) void decode_kernel(DecodeArgs a) {
   __threadfence();
   __syncthreads();
   // entries 1..T hold the winning word-end SLOT (0xFFFF: no surviving word end -> word 0, :118,191): map to words
+  bool bad = false;
   for (uint32_t t = 1 + tid; t <= T; t += NT) {
     const uint32_t sl = __hip_atomic_load(&a.tb_word[tb0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    a.tb_word[tb0 + t] = sl == 0xFFFFu ? (uint16_t)0 : (uint16_t)a.net.slot_word[sl];
+    uint16_t w = 0;
+    if (sl != 0xFFFFu) { if (sl < P) w = (uint16_t)a.net.slot_word[sl]; else bad = true; }
+    a.tb_word[tb0 + t] = w;
   }
+  if (bad) atomicOr(&a.out_flags[u], kFlagCorrupt);
   __threadfence();
   __syncthreads();
-  if (slow_taken) atomicOr(&a.out_flags[u], 1u);
-  if (tid == 0) {
-    uint32_t* words = a.out_words + f0;
-    uint32_t n = 0, t = T;
-    while (t > 0) {
-      const uint32_t w = __hip_atomic_load(&a.tb_word[tb0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (w != a.net.silence_word) words[n++] = w;
-      t = __hip_atomic_load(&a.tb_bkp[tb0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    for (uint32_t i = 0; i < n / 2; i++) { const uint32_t x = words[i]; words[i] = words[n - 1 - i]; words[n - 1 - i] = x; }
-    a.out_count[u] = n;
+  if (slow_taken) atomicOr(&a.out_flags[u], kFlagSlowPath);
+  if (tid == 0) {  // guarded walk: traceback.h
+    const uint32_t n = walk_traceback(
+        T, a.net.silence_word, a.net.n_words,
+        [&](uint32_t t) -> uint32_t { return __hip_atomic_load(&a.tb_word[tb0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
+        [&](uint32_t t) -> uint32_t { return __hip_atomic_load(&a.tb_bkp[tb0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
+        a.out_words + f0, T);
+    if (n == kTbCorrupt) atomicOr(&a.out_flags[u], kFlagCorrupt);
+    a.out_count[u] = n == kTbCorrupt ? 0u : n;
   }
-#ifdef SR_DECODE_STAMPS
-  if (tid == 0)
-    for (int k = 0; k < 6 && k + 1 <= (int)T; k++) a.tb_score[tb0 + 1 + k] = (double)stamp_sum[k];
-#endif
 }
 
 // ---- the same search for lexicons whose hypothesis arrays do not fit the LDS (more than 8192 slots) -----------------------
@@ -513,23 +487,25 @@ __global__ __launch_bounds__(NT) void decode_big_kernel(DecodeArgs a, unsigned c
   // ---- traceback (Recognizer.cpp:222-231) -------------------------------------------------------------
   __threadfence();
   __syncthreads();
+  bool bad = false;
   for (uint32_t t = 1 + tid; t <= T; t += NT) {
     const uint32_t sl = __hip_atomic_load(&a.tb_word[tb0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    a.tb_word[tb0 + t] = sl == 0xFFFFu ? (uint16_t)0 : (uint16_t)a.net.slot_word[sl];
+    uint16_t w = 0;
+    if (sl != 0xFFFFu) { if (sl < P) w = (uint16_t)a.net.slot_word[sl]; else bad = true; }
+    a.tb_word[tb0 + t] = w;
   }
+  if (bad) atomicOr(&a.out_flags[u], kFlagCorrupt);
   __threadfence();
   __syncthreads();
-  if (slow_taken) atomicOr(&a.out_flags[u], 1u);
-  if (tid == 0) {
-    uint32_t* words = a.out_words + f0;
-    uint32_t n = 0, t = T;
-    while (t > 0) {
-      const uint32_t w = __hip_atomic_load(&a.tb_word[tb0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (w != a.net.silence_word) words[n++] = w;
-      t = __hip_atomic_load(&a.tb_bkp[tb0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    for (uint32_t i = 0; i < n / 2; i++) { const uint32_t x = words[i]; words[i] = words[n - 1 - i]; words[n - 1 - i] = x; }
-    a.out_count[u] = n;
+  if (slow_taken) atomicOr(&a.out_flags[u], kFlagSlowPath);
+  if (tid == 0) {  // guarded walk: traceback.h
+    const uint32_t n = walk_traceback(
+        T, a.net.silence_word, a.net.n_words,
+        [&](uint32_t t) -> uint32_t { return __hip_atomic_load(&a.tb_word[tb0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
+        [&](uint32_t t) -> uint32_t { return __hip_atomic_load(&a.tb_bkp[tb0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
+        a.out_words + f0, T);
+    if (n == kTbCorrupt) atomicOr(&a.out_flags[u], kFlagCorrupt);
+    a.out_count[u] = n == kTbCorrupt ? 0u : n;
   }
 }
 
@@ -574,4 +550,30 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream) {
   return hipErrorInvalidValue;
 }
 
+}  // namespace srgpu
+
+// ---- the walk alone (sr_traceback_corpus): traceback arrays supplied by the caller, one thread per utterance ------------
+namespace srgpu {
+__global__ void traceback_kernel(const uint64_t* frame_off, uint32_t n_utts, const uint16_t* tb_word, const uint16_t* tb_bkp,
+                                 uint32_t silence_word, uint32_t n_words, uint32_t* out_words, uint32_t* out_count,
+                                 uint32_t* out_flags) {
+  const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= n_utts) return;
+  const uint64_t f0 = frame_off[u], tb0 = f0 + u;
+  const uint32_t T = (uint32_t)(frame_off[u + 1] - f0);
+  const uint32_t n = walk_traceback(
+      T, silence_word, n_words, [&](uint32_t t) -> uint32_t { return tb_word[tb0 + t]; },
+      [&](uint32_t t) -> uint32_t { return tb_bkp[tb0 + t]; }, out_words + f0, T);
+  out_flags[u] = n == kTbCorrupt ? kFlagCorrupt : 0u;
+  out_count[u] = n == kTbCorrupt ? 0u : n;
+}
+
+hipError_t launch_traceback(const uint64_t* frame_off, uint32_t n_utts, const uint16_t* tb_word, const uint16_t* tb_bkp,
+                            uint32_t silence_word, uint32_t n_words, uint32_t* out_words, uint32_t* out_count,
+                            uint32_t* out_flags, hipStream_t stream) {
+  if (n_utts == 0) return hipSuccess;
+  hipLaunchKernelGGL(traceback_kernel, dim3((n_utts + 63) / 64), dim3(64), 0, stream, frame_off, n_utts, tb_word, tb_bkp,
+                     silence_word, n_words, out_words, out_count, out_flags);
+  return hipGetLastError();
+}
 }  // namespace srgpu

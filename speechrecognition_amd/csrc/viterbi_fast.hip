@@ -16,28 +16,13 @@
 // Ties are broken by ORIGINAL slot index (the reference's visiting order), which every slot carries along.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "kernels.h"
+#include "traceback.h"
 
 namespace srgpu {
 
 static constexpr double kInfF = __builtin_huge_val();
-
-// Diagnostic build only (-DSR_DECODE_STAMPS, tools/decode_stamps.py): per-phase cycle sums of wave 0.
-#ifdef SR_DECODE_STAMPS
-#define SR_STAMP(k)                                                                     \
-  do {                                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                  \
-    const unsigned long long now_ = __builtin_amdgcn_s_memtime();                       \
-    __builtin_amdgcn_s_waitcnt(0xC07F);                                                 \
-    stamp_sum[k] += now_ - stamp_last;                                                  \
-    stamp_last = now_;                                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                                  \
-  } while (0)
-#else
-#define SR_STAMP(k) do {} while (0)
-#endif
 
 // ---- DPP helpers --------------------------------------------------------------------------------------
 template <int CTRL, int ROW_MASK>
@@ -181,9 +166,6 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
   }
   __syncthreads();
 
-#ifdef SR_DECODE_STAMPS
-  unsigned long long stamp_sum[6] = {0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
-#endif
   auto frame = [&](const uint32_t t) -> bool {
     const uint32_t* ef_cur = e_first + 4 * (t & 1);
     uint32_t* ef_nxt = e_first + 4 * ((t + 1) & 1);
@@ -194,7 +176,6 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
       for (int i = 0; i < SPT; i++) am_n[i] = rown[st[i]];
     }
 
-    SR_STAMP(0);
     // ---- A ----------------------------------------------------------------------------------------------
     double nv[SPT];
     uint32_t nb[SPT];
@@ -283,16 +264,13 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
     if (neg) *bail = 1;
     if (tid < 4) ef_nxt[tid] = 0xFFFFFFFFu;
 
-    SR_STAMP(1);
     // ---- B ----------------------------------------------------------------------------------------------
     my_best = wave_min_dpp(my_best);
     if (wave_has_we) wave_min_idx_dpp(my_we, my_we_idx);  // (other waves keep +inf / no index)
     if (lane == 0) { red_best[wave] = my_best; red_we[wave] = my_we; red_idx[wave] = my_we_idx; }
-    SR_STAMP(2);
     __syncthreads();
-    SR_STAMP(3);
     if (*bail) {  // workgroup-uniform: hand the utterance to the replay variant
-      if (tid == 0) { atomicOr(&a.out_flags[u], 2u); a.out_count[u] = 0; }
+      if (tid == 0) { atomicOr(&a.out_flags[u], kFlagReplay); a.out_count[u] = 0; }
       return true;
     }
     double best = red_best[lane & (NW - 1)], we = red_we[lane & (NW - 1)];
@@ -336,39 +314,35 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
       }
     }
     if (!we_alive && tid == 0) { a.tb_score[tb0 + t] = kInfF; a.tb_word[tb0 + t] = 0xFFFFu; a.tb_bkp[tb0 + t] = 0; }
-    SR_STAMP(4);
     __syncthreads();
-    SR_STAMP(5);
     return false;
   };
 
   for (uint32_t t = 1; t <= T; t++)
     if (frame(t)) return;
 
-  // ---- traceback (Recognizer.cpp:222-231) --------------------------------------------------------------------
+  // ---- traceback (Recognizer.cpp:222-231; guarded walk: traceback.h) -------------------------------------------
   __threadfence();
   __syncthreads();
+  bool bad = false;
   for (uint32_t t = 1 + tid; t <= T; t += NT) {  // winning slot -> word
     const uint32_t sl = __hip_atomic_load(&a.tb_word[tb0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    a.tb_word[tb0 + t] = sl == 0xFFFFu ? (uint16_t)0 : (uint16_t)net.word[sl];
+    uint16_t w = 0;  // 0xFFFF: no surviving word end -> Book(inf, 0, 0), :118,191
+    if (sl != 0xFFFFu) { if (sl < net.n_slots) w = (uint16_t)net.word[sl]; else bad = true; }
+    a.tb_word[tb0 + t] = w;
   }
+  if (bad) atomicOr(&a.out_flags[u], kFlagCorrupt);
   __threadfence();
   __syncthreads();
   if (tid == 0) {
-    uint32_t* words = a.out_words + f0;
-    uint32_t n = 0, t = T;
-    while (t > 0) {
-      const uint32_t w = __hip_atomic_load(&a.tb_word[tb0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (w != a.net.silence_word) words[n++] = w;
-      t = __hip_atomic_load(&a.tb_bkp[tb0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    for (uint32_t i = 0; i < n / 2; i++) { const uint32_t x = words[i]; words[i] = words[n - 1 - i]; words[n - 1 - i] = x; }
-    a.out_count[u] = n;
+    const uint32_t n = walk_traceback(
+        T, a.net.silence_word, a.net.n_words,
+        [&](uint32_t t) -> uint32_t { return __hip_atomic_load(&a.tb_word[tb0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
+        [&](uint32_t t) -> uint32_t { return __hip_atomic_load(&a.tb_bkp[tb0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
+        a.out_words + f0, T);
+    if (n == kTbCorrupt) atomicOr(&a.out_flags[u], kFlagCorrupt);
+    a.out_count[u] = n == kTbCorrupt ? 0u : n;
   }
-#ifdef SR_DECODE_STAMPS
-  if (tid == 0)
-    for (int k = 0; k < 6 && k + 1 <= (int)T; k++) a.tb_score[tb0 + 1 + k] = (double)stamp_sum[k];
-#endif
 }
 
 static size_t fast_smem(uint32_t PP) { return (size_t)PP * 16 + 16 * 8 * 2 + 16 * 4 + 12 * 4 + (size_t)PP * 2 + 16; }
@@ -385,17 +359,6 @@ hipError_t launch_decode_fast(const DecodeArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL((decode_fast_kernel<NT, SPT>), grid, dim3(NT), smem, stream, a);                                 \
     return hipGetLastError();                                                                                           \
   } while (0)
-  static const int geom = getenv("SRGPU_DECODE_GEOM") ? atoi(getenv("SRGPU_DECODE_GEOM")) : 0;  // A/B timing: threads * 100 + slots per thread
-  if (geom == 102404 && P <= 4096) SR_LAUNCH(1024, 4);
-  if (geom == 51208 && P <= 4096) SR_LAUNCH(512, 8);
-  if (geom == 25616 && P <= 4096) SR_LAUNCH(256, 16);
-  if (geom == 102402 && P <= 2048) SR_LAUNCH(1024, 2);
-  if (geom == 51204 && P <= 2048) SR_LAUNCH(512, 4);
-  if (geom == 25608 && P <= 2048) SR_LAUNCH(256, 8);
-  if (geom == 102401 && P <= 1024) SR_LAUNCH(1024, 1);
-  if (geom == 25604 && P <= 1024) SR_LAUNCH(256, 4);
-  if (geom == 25601 && P <= 256) SR_LAUNCH(256, 1);
-  if (geom == 6404 && P <= 256) SR_LAUNCH(64, 4);
   if (a.n_utts <= 256) {
     // At most one utterance per CU: the frame loop is a chain of dependent steps, and the widest workgroup makes it shortest
     // (one 10 000-frame utterance, us per frame: P = 1216: 3.11 at 256 x 8, 2.24 at 512 x 4, 1.98 at 1024 x 2; P = 448: 1.97 at

@@ -5,7 +5,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from speechrecognition_amd import capi, synth
+from speechrecognition_amd import capi, sharding, synth
 from tests.util import Case
 
 pytestmark = pytest.mark.gpu
@@ -177,3 +177,45 @@ def test_device_finalize_equals_host_finalize(name, tmp_path, monkeypatch):
     with capi.Model.from_statistics(c.dim, topo[0], topo[1], topo[2], acc, pooling=c.pooling, max_approx=c.max_approx) as m2:
         assert np.array_equal(m2.score_frames(c.feats, capi.GMM_EXACT).view(np.uint64), dev.view(np.uint64))
         assert np.array_equal(m2.score_frames(c.feats, capi.GMM_PREFILTER).view(np.uint64), dev.view(np.uint64))
+
+
+def test_cfg4_ten_thousand_utterances_eight_replicas(tmp_path, oracle_lib):
+    """BASELINE configs[3]: 4000 states x 32, ONE batch of 10 000 utterances (U{200..400} frames, 3.0 M frames) sharded eight
+    ways -- sr_recognize_batch_multi with eight (model, lexicon) replicas, all on device 0 here, one per GPU in production
+    (Recognizer.cpp:43-56: the utterance loop, parallel over segments).  Against the single-handle path (three score chunks)
+    on every word, against sr_shard_utterances on the deal, and against the CPU oracle on sampled utterances including the
+    longest, the shortest and the last utterance of a shard."""
+    lex = synth.make_lexicon(1333, 3, 1)
+    spec = synth.make_mixset(lex.n_states, 32, 39, seed=23)
+    mp = str(tmp_path / "cfg4.mix")
+    synth.write_mixset(mp, spec)
+    feats, off = synth.make_batch(10000, 200, 400, 39, seed=7)
+    assert int(off[-1]) > 2_900_000
+    word_off, automaton, sil = lex.flatten()
+    R = 8
+    models = [capi.Model.from_mixset(mp, 39) for _ in range(R)]
+    lexica = [m.lexicon(word_off, automaton, lex.silence_idx, TDP, sil) for m in models]
+    try:
+        w8, o8, load = capi.recognize_batch_multi(models, lexica, feats, off, 200.0, 10.0)
+        shard_of, want_load = capi.shard_utterances(off, R)
+        assert np.array_equal(load, want_load) and int(load.sum()) == int(off[-1])
+        assert load.max() / load.mean() < 1.002
+        assert np.bincount(shard_of, minlength=R).min() >= 1200   # ~1250 utterances per shard
+        w1, o1 = models[0].recognize_batch(lexica[0], feats, off, 200.0, 10.0)
+        assert np.array_equal(o8, o1) and np.array_equal(w8, w1) and len(w1) > 500_000
+    finally:
+        for l in lexica:
+            l.close()
+        for m in models:
+            m.close()
+    lens = np.diff(off.astype(np.int64))
+    rng = np.random.default_rng(1)
+    sample = {int(np.argmax(lens)), int(np.argmin(lens)), 0, 9999, int(np.flatnonzero(shard_of == 0)[-1]),
+              int(np.flatnonzero(shard_of == R - 1)[-1])} | {int(u) for u in rng.integers(0, 10000, size=4)}
+    sample = sorted(sample)
+    sub, sub_off = sharding.take_shard(feats, off, sample)
+    o = oracle_lib.Oracle(mp, 39, lex, tdp=TDP, am_threshold=200.0, word_penalty=10.0)
+    ow, ooff, _ = o.recognize_batch(sub, sub_off, n_threads=min(16, len(sample)))
+    o.close()
+    for i, u in enumerate(sample):
+        assert np.array_equal(ow[int(ooff[i]):int(ooff[i + 1])], w8[int(o8[u]):int(o8[u + 1])]), f"utterance {u}"
