@@ -63,7 +63,7 @@ def parse():
     ap.add_argument("--no-dense-mfma", action="store_true", help="skip the one untimed step through the dense FP64 MFMA kernel")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals "
                     "where several ranks share one GPU)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget of the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall budget of the all-core cpu_baseline leg (the one-thread leg adds one short utterance)")
     args = ap.parse_args()
     if args.config == "cfg4":
         args.total_utts = 10000
@@ -277,6 +277,7 @@ def gmm_roofline(args, prof, n_frames, D, S):
         return {"kernel": "gmm_refine_kernel", "bound": "valu", "achieved": achieved, "peak": FP64_VALU_UNFUSED_PEAK,
                 "unit": "TFLOP/s", "frac": achieved / FP64_VALU_UNFUSED_PEAK, "traffic": pmc_traffic(args, n_frames, "gmm_refine_kernel"),
                 "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, KB units, separate rocprofv3 --pmc passes)",
+                "traffic_source": traffic_source(args, n_frames),
                 "launches": prof["gmm_launches"], "avg_launch_ms": ms,
                 "flops_per_frame": 4.0 * D * S, "dtype": "f64 unfused add/mul",
                 "note": "dominant kernel of the step; it is bound by the FP64 vector pipe (no MFMA, HBM traffic hidden), which "
@@ -362,20 +363,55 @@ def prefilter_report(args, prof, n_frames, D, S):
     }
 
 
+def kernel_sources_sha16():
+    """sha256 over the device sources, as tools/summarize_profile.py stamps a profile with."""
+    import hashlib
+    csrc = os.path.join(ROOT, "speechrecognition_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+PMC_SUMMARIES = {"prefilter": ("r3_prefilter_summary.json", "r2_prefilter_summary.json"), "mfma": ("r1_mfma_summary.json",)}
+
+
+def pmc_summary(args, n_frames):
+    """The PMC summary under profiles/ (tools/profile_bench.sh; rocprofv3 cannot run inside the timed process) that belongs to
+    THIS workload and to THESE kernel sources, or None: counters taken before a kernel changed are not reported."""
+    for name in PMC_SUMMARIES.get(args.kernel, ()):
+        try:
+            z = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        if z.get("workload_frames_per_launch") != n_frames or args.words != 1333 or args.mix != 32:
+            continue
+        if z.get("kernel_sources_sha16") != kernel_sources_sha16():
+            continue
+        z["_file"] = "profiles/" + name
+        return z
+    return None
+
+
 def pmc_traffic(args, n_frames, kernel="gmm_mfma_kernel"):
-    """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ (tools/profile_bench.sh;
-    rocprofv3 cannot run inside the timed process); only reported when they were taken on this very workload."""
-    path = os.path.join(ROOT, "profiles", "r2_prefilter_summary.json" if args.kernel == "prefilter" else "r1_mfma_summary.json")
-    try:
-        z = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    if z.get("workload_frames_per_launch") != n_frames or args.words != 1333 or args.mix != 32:
+    """HBM bytes per launch of `kernel` from the PMC passes committed under profiles/ -- only when they were taken on this
+    very workload with the kernel sources of this tree (the summary carries their hash and commit)."""
+    z = pmc_summary(args, n_frames)
+    if z is None:
         return None
     for name, k in z.get("kernels", {}).items():
         if name.startswith(kernel):
             return k.get("hbm_bytes_per_launch_corrected")
     return None
+
+
+def traffic_source(args, n_frames):
+    z = pmc_summary(args, n_frames)
+    if z is None:
+        return "none: no PMC summary under profiles/ matches this workload and these kernel sources (sha %s)" % kernel_sources_sha16()
+    return {"file": z["_file"], "git_head": z.get("git_head"), "kernel_sources_sha16": z.get("kernel_sources_sha16")}
 
 
 def usable_cores():
@@ -391,21 +427,41 @@ def usable_cores():
     return max(1, min(n, 16))
 
 
+def cpu_model():
+    """(model name, logical CPUs of the host) from /proc/cpuinfo -- SURVEY 8(d): "core count and CPU model printed"."""
+    name, n = "unknown", 0
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                n += 1
+                name = line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return name, n
+
+
 def cpu_baseline(args, mixset_path, lex, tdp, wp, feats, frame_off, gpu_words, gpu_woff):
-    """The CPU oracle's utterance loop (the reference's timed region, Recognizer.cpp:45-80) with the
-    reference's strategy (OpenMP over utterances, :46) on a bounded sample of the same batch; the
-    sample's words are also checked against the GPU's."""
+    """The CPU oracle's utterance loop (the reference's timed region, Recognizer.cpp:45-80) on a bounded sample of the same
+    batch, SURVEY 8(d)'s two legs: (i) ONE thread -- the shortest utterance, which also yields the reference's lazy-scoring
+    fraction (scorer calls / (frames x states): its am_cache scores only states a live hypothesis touches,
+    Recognizer.cpp:123,148-151,178-181) -- and (ii) all usable cores with the reference's strategy (OpenMP
+    schedule(dynamic) over utterances, :46).  The sample's words are checked against the GPU's."""
     from oracle import pyoracle
 
     cores = usable_cores()
+    model_name, host_cpus = cpu_model()
     orc = pyoracle.Oracle(mixset_path, 39, lex, tdp=tdp, am_threshold=args.beam, word_penalty=wp)
-    # calibrate on one short utterance, single thread
     lens = np.diff(frame_off.astype(np.int64))
     u0 = int(np.argmin(lens))
     f0 = feats[int(frame_off[u0]):int(frame_off[u0 + 1])]
     t = time.perf_counter()
-    orc.decode(f0)
-    per_frame = (time.perf_counter() - t) / max(1, len(f0))
+    w0 = orc.decode(f0)
+    secs1 = time.perf_counter() - t
+    per_frame = secs1 / max(1, len(f0))
+    lazy = orc.last_n_scored / float(max(1, len(f0)) * lex.n_states)
+    one = {"value": len(f0) / secs1, "unit": "frames/s", "cores": 1,
+           "sample": f"utterance {u0} (the shortest: {len(f0)} frames), {secs1:.1f} s wall",
+           "words_match_gpu": bool(np.array_equal(w0, gpu_words[int(gpu_woff[u0]):int(gpu_woff[u0 + 1])]))}
     budget_frames = args.cpu_seconds * cores / max(per_frame, 1e-9)
     n = int(np.searchsorted(frame_off[1:].astype(np.float64), budget_frames)) + 1
     n = max(min(n, len(lens)), min(cores, len(lens)))
@@ -423,6 +479,15 @@ def cpu_baseline(args, mixset_path, lex, tdp, wp, feats, frame_off, gpu_words, g
         "sample": f"first {n} of {len(lens)} utterances ({int(sub_off[-1])} frames), lazy scoring + beam {args.beam:g}, "
                   f"OpenMP schedule(dynamic) over utterances, {secs:.1f} s wall",
         "words_match_gpu": match,
+        "cpu_model": model_name,
+        "host_logical_cpus": host_cpus,
+        "one_thread": one,
+        "reference_equivalent": {
+            "lazy_scored_fraction": lazy,
+            "note": "share of the (frame, state) pairs the reference's lazy am_cache scores at this beam (measured by the oracle on the "
+                    "one-thread utterance); the GPU scores every pair, so its reference-equivalent rate is `value` of this line "
+                    "in frames/s either way and its dense density-evaluation rate is 1/fraction of the reference-equivalent one",
+        },
     }
 
 

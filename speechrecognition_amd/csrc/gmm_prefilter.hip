@@ -384,10 +384,12 @@ int gmm_prefilter_frames_per_tile() { return kPWaves * SR_P16_NB * 16; }
 // the CU's LDS once (160 KiB for 8 states x 32 densities x 39 dimensions), and streams frames through its threads:
 // one frame per thread at a time, the feature vector converted to FP64 and kept in registers, one 64-byte piece of
 // the output row per frame.  No barrier and no refill inside the frame loop.
-// LDS image per state: planes [mu_0 | 1/var_0 | mu_1 | 1/var_1 | ... | norm | logw] of NS density slots each.  A lane
-// that evaluates density d of state s reads plane[p][(d + s) mod NS] with ds_read_b64, whose bank pair is that slot
-// mod 32: lanes on different densities of ONE state never conflict and lanes on the same density share one broadcast
-// read -- so every wave instruction below evaluates candidates of a single state.
+// LDS image per state: planes [mu_0 | 1/var_0 | mu_1 | 1/var_1 | ... | norm | logw] of NS density slots each, density d in
+// slot d.  A lane that evaluates density d reads plane[p][d] with ds_read_b64, whose bank pair is d mod 32: lanes on different
+// densities of ONE state never conflict and lanes on the same density share one broadcast read -- so every wave instruction
+// below evaluates candidates of a single state.  (A bit of the candidate mask beyond the state's densities is cleared before
+// it is used; the guard bit of ctz(mask | 2^31) can only be reached by a lane whose result is discarded, and slot 31 of a
+// narrower image is still inside the workgroup's LDS.)
 //
 // Work layout (round 2).  About 7 % of the (frame, state) pairs have more than one candidate.  Letting the lanes that
 // hold such pairs loop (round 1) cost 0.44 extra wave-evaluations per pair-wave for 0.087 extra candidates, because a
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
   __syncthreads();
   if (f_begin >= f_end) return;  // (after the barrier: whole workgroup)
 
-  uint32_t n_eval = 0;
+  uint32_t n_eval = 0;  // evaluations of this WAVE (profiling; a scalar: counted by ballots, no per-lane arithmetic)
   double x[DT ? DT : 1];
   uint64_t fx = 0;  // frame whose features x[] / X() hold
   bool fx_T = true; // (run-time dimension only) X() reads it from featsT / from the row-major buffer
@@ -557,6 +559,15 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
     return score;
   };
 
+  // min_score's `if (score < min_score)` from the seed 1e10 (Mixtures.cpp:699-708) for the first candidate: v_min_f64 returns the
+  // other operand for a NaN, i.e. the seed, exactly what the strict comparison leaves; one instruction instead of a compare and
+  // two selects
+  const double seed = 1e10;
+  auto seeded_min = [&](double score) -> double {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(score), "s"(seed));
+    return r;
+  };
   // ---- wave-private candidate lists (global memory, a few KB per wave: L1/L2 resident) -----------------------------
   // an entry = (frame, candidates still to evaluate, best score so far): the batches need no look-up in the mask array or
   // the score table, they only store to the table where a later candidate wins
@@ -588,9 +599,11 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
         mask &= n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);  // padding slots of the prefilter are not densities
         res[j] = 1e10;  // min_score seed (Mixtures.cpp:699)
         if (n) {        // wave-uniform (a state without densities has an empty mask and keeps the seed)
-          const double score = evaluate(panel_raw + (size_t)j * state_bytes + ((__builtin_ctz(mask | 0x80000000u) + s0 + j) & (NS - 1)) * 8u);
-          if (mask != 0 && score < res[j]) res[j] = score;
-          if (counting) n_eval += (valid && mask != 0) ? 1u : 0u;
+          // (mask != 0 here: the prefilter keeps the approximate arg-min a candidate -- or everything, when the frame or the
+          // state is not a number -- and padding slots score +inf)
+          const double score = evaluate(panel_raw + (size_t)j * state_bytes + (uint32_t)__builtin_ctz(mask | 0x80000000u) * 8u);
+          res[j] = mask != 0 ? seeded_min(score) : res[j];
+          if (counting) n_eval += (uint32_t)__builtin_popcountll(__ballot(valid));  // (mask != 0, see above)
         }
         const bool more = valid && (mask & (mask - 1)) != 0;
         const uint64_t b = __ballot(more);
@@ -685,8 +698,9 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
       const double before = cur;
       const unsigned char* panel = panel_raw + (size_t)j * state_bytes;
       do {  // level 1: exactly one round (every live lane has a second candidate); level 2: until every lane is done
-        const double score = evaluate(panel + ((__builtin_ctz(m | 0x80000000u) + s0 + j) & (NS - 1)) * 8u);
-        if (m != 0) { if (counting) n_eval++; if (score < cur) cur = score; }
+        const double score = evaluate(panel + (uint32_t)__builtin_ctz(m | 0x80000000u) * 8u);
+        if (counting) n_eval += (uint32_t)__builtin_popcountll(__ballot(m != 0));
+        if (m != 0 && score < cur) cur = score;
         m &= m - 1;
       } while (!l1 && __any(m != 0));
       if (l1) {
@@ -708,8 +722,6 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
     }
   }
   if (a.n_refined) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) n_eval += __shfl_xor(n_eval, o);
     if (lane == 0) atomicAdd(a.n_refined, (unsigned long long)n_eval);
   }
 }

@@ -173,9 +173,10 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
       std::fill(r, r + (size_t)planes * NS, 0.0);
       for (uint32_t i = 0; i < ps_count(ps); i++) {
         const size_t c = (size_t)dens_off[ps / Cs] + 32u * (ps % Cs) + i;
-        // density i sits in slot (i + ps) mod NS: the workgroup's 8 states are rotated against each other, so that
-        // lanes on the same density index of different states (the refinement's phase 2) use different LDS banks
-        const uint32_t sl = (i + ps) & (NS - 1);
+        // density i sits in slot i (round 1 rotated a workgroup's states against each other for a phase in which a wave
+        // instruction mixed states; since round 2 every wave instruction evaluates candidates of ONE state, so lanes on
+        // different densities hit different bank pairs and lanes on the same density share a broadcast read as it is)
+        const uint32_t sl = i;
         for (uint32_t d = 0; d < D; d++) { r[(2 * d) * NS + sl] = means[c * D + d]; r[(2 * d + 1) * NS + sl] = inv_vars[c * D + d]; }
         r[(2 * D) * NS + sl] = norm[c];
         r[(2 * D + 1) * NS + sl] = logw[c];

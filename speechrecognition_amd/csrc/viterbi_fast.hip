@@ -23,6 +23,8 @@
 namespace srgpu {
 
 static constexpr double kInfF = __builtin_huge_val();
+// LDS of decode_fast_kernel before the row buffers: scores, the minima cells, first-index cells, flag, back pointers
+__host__ __device__ constexpr size_t fast_smem_base(uint32_t PP) { return (size_t)PP * 8 + 4 * 8 + 2 * 4 + 8 * 4 + 2 * 4 + (size_t)PP * 4 + 16; }
 
 // ---- DPP helpers --------------------------------------------------------------------------------------
 template <int CTRL, int ROW_MASK>
@@ -44,6 +46,10 @@ __device__ inline double dmin(double a, double b) {
   return r;
 }
 __device__ inline uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+// LDS ds_min_f64, no return value (the cell is read after the workgroup barrier)
+__device__ inline void atomic_min_f64_lds(double* cell, double v) {
+  asm volatile("ds_min_f64 %0, %1" : : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)cell), "v"(v) : "memory");
+}
 // full-wave minimum, returned to every lane
 __device__ inline double wave_min_dpp(double v) {
   v = dmin(v, dpp_d<0xB1, 0xF>(v));    // quad_perm [1,0,3,2]
@@ -97,19 +103,48 @@ static constexpr uint32_t kTSilState = 8u, kTSilWord = 16u, kTFirstSil = 32u;
 template <uint32_t K> struct KindC { __device__ constexpr operator uint32_t() const { return K; } };  // a slot kind known at compile time
 struct KindR { uint32_t v; __device__ operator uint32_t() const { return v; } };                          // ... or only at run time
 
-template <int NT, int SPT>
+// One hypothesis in LDS: its score and its back pointer, in two arrays (consecutive lanes -> consecutive words: conflict-free;
+// a 16-byte {score, bkp} cell was tried first and cost 4e8 bank-conflict cycles per launch, the compiler splits it into a b64
+// and a b32 access at a 16-byte stride).  Round 2 also kept a copy of the frame's emission costs there.
+struct Cell { double score; uint32_t bkp; };
+
+// Round 3 ("instruction diet"): the frame loop was 260 vector instructions per wave and frame for 4 slots per
+// lane; this version issues ~90.  What went:
+//   * the emission cost of a slot stays in a register from its (one frame ahead) gather; position-1 slots gather position
+//     0's cost themselves (the boundary quirk, Recognizer.cpp:148-151) instead of reading it from an LDS copy every slot wrote;
+//   * candidates merge as v_min_f64 + one compare + one select of the back pointer (first-wins ties = strict '<' on the later
+//     candidate), not compare + three selects; the word-boundary candidate is one add per slot -- (m_we + wp) + tdp is computed
+//     once per wave and frame -- and is skipped altogether while no word end is alive; its tie order against the in-word
+//     candidates (first word-end index per class vs. the slot's own word) is only looked at when a tie is there;
+//   * "emission cost < 0 or NaN" (the fast path's premise, see the file header) is one compare per slot into a scalar mask
+//     that is looked at once, after the last frame, instead of an LDS flag and a workgroup-uniform branch per frame;
+//   * the block minimum and the word-end minimum are LDS ds_min_f64 cells (by frame parity) fed by four lanes per wave after a
+//     row-level DPP reduction: no partials array, no second reduction after the barrier, no index reduction at all -- the FIRST
+//     minimal word end is found by the (one or two) lanes that hold the minimum, through an LDS atomic min on their original
+//     index, and the traceback entry of frame t is written at the top of frame t + 1 by the lane that won;
+//   * padding lanes cost two selects only in the chunks that have any.
+//   * ROWS (round 3, after the diet left the time where it was): the frame's emission costs used to be gathered from the score
+//     table by every slot -- 85 wave-wide 8-byte gathers per frame and workgroup at a 24-byte stride, each a dozen cache lines:
+//     the waves spent 2 000-3 500 cycles per frame at the top of the loop behind the texture-address queue
+//     (profiles/r3_decoder_diet.txt).  Now the whole row of frame t + 1 (states x 8 bytes, contiguous) is copied into LDS by
+//     LDS-DMA during frame t -- 1 KB per wave instruction, no registers -- and a slot reads its cost with one ds_read_b64.
+//     Rows that do not fit twice beside the hypotheses (S > ~6 000) keep the gathers (ROWS = false).
+template <int NT, int SPT, bool ROWS>
 __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr uint32_t PP = NT * SPT, NW = NT / 64;
+  constexpr uint32_t PP = NT * SPT;
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  double* sc = reinterpret_cast<double*>(smem);                  // [PP] hypothesis scores
-  double* am_l = sc + PP;                                        // [PP] emission cost of the current frame per slot
-  double* red_best = am_l + PP;                                  // [16]
-  double* red_we = red_best + 16;                                // [16]
-  uint32_t* red_idx = reinterpret_cast<uint32_t*>(red_we + 16);  // [16]
-  uint32_t* e_first = red_idx + 16;                              // [2][4] first word-end ORIGINAL index per class, by frame parity
-  uint32_t* bail = e_first + 8;                                  // [1]
-  uint16_t* bk = reinterpret_cast<uint16_t*>(e_first + 12);      // [PP] back pointers
+  double* sc = reinterpret_cast<double*>(smem);                     // [PP] hypothesis scores
+  double* c_best = sc + PP;                                         // [2] block minimum of the frame's new scores, by frame parity
+  double* c_we = c_best + 2;                                        // [2] minimum over word-end slots
+  uint32_t* c_widx = reinterpret_cast<uint32_t*>(c_we + 2);         // [2] first ORIGINAL index among the minimal word ends
+  uint32_t* e_first = c_widx + 2;                                   // [2][4] first word-end original index per class, by frame parity
+  uint32_t* s_bad = e_first + 8;                                    // [1] some emission cost was negative or NaN
+  uint32_t* bk = s_bad + 2;                                         // [PP] back pointers
+  // ROWS: two row buffers (frame parity) behind the hypotheses, 1 KB granular (one LDS-DMA piece = 64 lanes x 16 bytes)
+  const uint32_t row_bytes = a.ld * 8u, row_pad = (row_bytes + 1023u) & ~1023u;
+  unsigned char* rows_lds = smem + ((fast_smem_base(PP) + 1023u) & ~(size_t)1023u);
+  auto cell = [&](uint32_t p) -> Cell { return Cell{sc[p], bk[p]}; };
 
   const FastNet& net = a.fast;
   const uint32_t u = a.utt_order ? a.utt_order[a.utt_first + blockIdx.x] : a.utt_first + blockIdx.x;
@@ -121,22 +156,24 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
   const double wp_word = a.word_penalty, thr = a.am_threshold;
 
   // Slot of (thread, i): a wave owns SPT consecutive 64-slot chunks of the type-sorted net, so most waves hold one kind (the
-  // straight-line path below) and only the waves that hold word-end kinds pay for the word-end reduction.  (Round 1 dealt the
-  // chunks round-robin when few utterances were in flight, so that every wave carried the same mix of kinds; with the
-  // straight-line path the consecutive deal is faster there too: 2.04 -> 1.87 us per frame for one utterance of configs[1],
-  // 1.68 -> 1.49 ms for 64 utterances of configs[2].)
+  // straight-line path below) and only the waves that hold word-end kinds pay for the word-end reduction.
   auto slot_of = [&](int i) -> uint32_t { return (wave * SPT + (uint32_t)i) * 64 + lane; };
   // ---- static per-slot constants ------------------------------------------------------------------------
-  uint32_t st[SPT], pr[SPT], og[SPT], ty[SPT];
+  uint32_t st[SPT], st0[SPT], p1[SPT], p2[SPT], og[SPT], ty[SPT];
+  uint32_t pad_chunks = 0;  // wave-uniform: bit i = chunk i of this wave has padding lanes
 #pragma unroll
   for (int i = 0; i < SPT; i++) {
     const uint32_t p = slot_of(i);
     const bool in = p < net.n_slots;
     st[i] = in ? net.state[p] : 0u;      // padding slots read state 0: a valid address, value unused
-    pr[i] = in ? net.pred[p] : (p | (p << 16));
+    const uint32_t pr = in ? net.pred[p] : (p | (p << 16));
+    p1[i] = pr & 0xFFFFu; p2[i] = pr >> 16;
     og[i] = in ? net.orig[p] : 0xFFFFFFFFu;
     ty[i] = __builtin_amdgcn_readfirstlane(in ? net.chunk_type[p >> 6] : kPad);  // one type per 64-slot chunk
-    sc[p] = kInfF; bk[p] = 0;
+    const uint32_t kind = ty[i] & kKindMask;
+    st0[i] = (kind == kE1 || kind == kE1E) ? net.state[p1[i]] : st[i];            // emission state of the word's position 0
+    if (__any(og[i] == 0xFFFFFFFFu)) pad_chunks |= 1u << i;
+    sc[p] = kInfF; bk[p] = 0u;
   }
   bool uniform_kind = true;  // wave-uniform: all of this wave's chunks have the same type word
 #pragma unroll
@@ -148,99 +185,145 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
     wave_has_we |= (kind == kE0S || kind == kE1E || kind == kME);
   }
   if (tid < 8) e_first[tid] = 0xFFFFFFFFu;
-  if (tid == 8) *bail = 0;
+  if (tid < 2) { c_best[tid] = kInfF; c_we[tid] = kInfF; c_widx[tid] = 0xFFFFFFFFu; }
+  if (tid == 8) *s_bad = 0;
   __syncthreads();
   const bool init_is_end = net.init_is_end;
-  double m_we = init_is_end ? 0.0 : kInfF;
+  double m_we = init_is_end ? 0.0 : kInfF;  // minimum over the word ends that survived the previous frame (uniform)
   if (tid == 0) {
     sc[net.init_slot] = 0.0;  // initial hypothesis: word 0, position 0, score 0 (Recognizer.cpp:120)
     a.tb_score[tb0] = 0.0; a.tb_word[tb0] = 0; a.tb_bkp[tb0] = 0;
   }
   if (tid < 4 && init_is_end) e_first[4 + tid] = 0;
-  double am_n[SPT];  // emission gathers one frame ahead: frame t+1's costs are issued at the top of frame t
+  // emission costs one frame ahead: the row (ROWS) or the gathers of frame t + 1 are issued at the top of frame t
+  auto issue_row = [&](uint32_t frame /* 1-based */) {  // row of `frame` -> buffer frame & 1; every wave copies its share of the pieces
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(row0 + (uint64_t)(frame - 1) * a.ld);
+    unsigned char* dst = rows_lds + (frame & 1u) * row_pad;
+    for (uint32_t piece = wave; piece * 1024u < row_bytes; piece += NT / 64) {
+      const uint32_t off = piece * 1024u + lane * 16u;
+      if (off < row_bytes)  // (a row is a multiple of 64 bytes; the last piece may be short)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
+                                         (__attribute__((address_space(3))) void*)(dst + piece * 1024u), 16, 0, 0);
+    }
+  };
+  double am_c[SPT], am0_c[SPT];
 #pragma unroll
   for (int i = 0; i < SPT; i++) {
-    const uint32_t p = slot_of(i);
-    am_n[i] = T > 0 ? row0[st[i]] : 0.0;
-    am_l[p] = am_n[i];
+    const uint32_t kind = ty[i] & kKindMask;
+    am_c[i] = (!ROWS && T > 0) ? row0[st[i]] : 0.0;
+    am0_c[i] = (!ROWS && T > 0 && (kind == kE1 || kind == kE1E)) ? row0[st0[i]] : am_c[i];
   }
+  if (ROWS && T > 0) { issue_row(1); __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0)
   __syncthreads();
 
-  auto frame = [&](const uint32_t t) -> bool {
-    const uint32_t* ef_cur = e_first + 4 * (t & 1);
-    uint32_t* ef_nxt = e_first + 4 * ((t + 1) & 1);
-    const uint32_t bkp_new = (t - 1) & 0xFFFFu;
-    if (t + 1 <= T) {
-      const double* rown = row0 + (uint64_t)t * a.ld;  // frame t+1
-#pragma unroll
-      for (int i = 0; i < SPT; i++) am_n[i] = rown[st[i]];
+  uint64_t bad = 0;        // lanes that met an emission cost that is not >= 0 (scalar mask, looked at after the last frame)
+  // the lane that may own traceback[t - 1] (it held the word-end minimum of the previous frame): written at the top of frame t
+  bool pend = false;
+  uint32_t pend_o = 0, pend_p = 0, pend_b = 0;
+  double pend_v = 0.0;
+  bool prev_alive = true;  // frame 0: traceback[0] is written above
+  auto flush_pending = [&](const uint32_t t_prev) {  // t_prev >= 1
+    if (__any(pend)) {  // wave-uniform, about one wave per frame
+      if (pend && c_widx[t_prev & 1] == pend_o) {
+        a.tb_score[tb0 + t_prev] = pend_v; a.tb_word[tb0 + t_prev] = (uint16_t)pend_p; a.tb_bkp[tb0 + t_prev] = (uint16_t)pend_b;
+      }
+      pend = false;
     }
+    if (!prev_alive && tid == 0) { a.tb_score[tb0 + t_prev] = kInfF; a.tb_word[tb0 + t_prev] = 0xFFFFu; a.tb_bkp[tb0 + t_prev] = 0; }
+  };
 
-    // ---- A ----------------------------------------------------------------------------------------------
+  for (uint32_t t = 1; t <= T; t++) {
+    const uint32_t par = t & 1;
+    const uint32_t* ef_cur = e_first + 4 * par;
+    uint32_t* ef_nxt = e_first + 4 * (par ^ 1);
+    const uint32_t bkp_new = (t - 1) & 0xFFFFu;
+    double am[SPT], am0[SPT];
+#pragma unroll
+    for (int i = 0; i < SPT; i++) { am[i] = am_c[i]; am0[i] = am0_c[i]; }
+    if (t + 1 <= T) {
+      if (ROWS) {
+        issue_row(t + 1);
+      } else {
+        const double* rown = row0 + (uint64_t)t * a.ld;  // frame t + 1
+#pragma unroll
+        for (int i = 0; i < SPT; i++) {
+          const uint32_t kind = ty[i] & kKindMask;
+          am_c[i] = rown[st[i]];
+          if (kind == kE1 || kind == kE1E) am0_c[i] = rown[st0[i]];
+        }
+      }
+    }
+    const double* row_l = reinterpret_cast<const double*>(rows_lds + par * row_pad);  // ROWS: this frame's row
+    if (t > 1) flush_pending(t - 1);
+    if (tid < 4) ef_nxt[tid] = 0xFFFFFFFFu;
+    if (tid == 4) { c_best[par ^ 1] = kInfF; c_we[par ^ 1] = kInfF; c_widx[par] = 0xFFFFFFFFu; }
+
+    // ---- A: candidates of every slot --------------------------------------------------------------------------
     double nv[SPT];
     uint32_t nb[SPT];
     double my_best = kInfF, my_we = kInfF;
-    uint32_t my_we_idx = 0xFFFFFFFFu;
-    bool neg = false;
-    // one slot's candidates; `kind` is wave-uniform -- a run-time scalar (KindR) or a compile-time constant (KindC)
+    const bool we_in = m_we != kInfF;  // uniform: a word end survived the previous frame -- else there is no boundary candidate
+    // one slot; `kind` is wave-uniform -- a run-time scalar (KindR) or a compile-time constant (KindC)
     auto slot_a = [&](const auto kind, const uint32_t type, const int i) __attribute__((always_inline)) {
       const uint32_t p = slot_of(i);
-      const double am = am_l[p];
-      neg |= am < 0.0;
+      const double e = ROWS ? row_l[st[i]] : am[i];
+      bad |= __ballot(!(e >= 0.0));
       const bool sil = type & kTSilState;
       const double t_loop = sil ? tf : tl, t_skip = sil ? tf : ts;  // scalars: TdpModel.cpp:19-29 keyed on the destination
-      const uint32_t p1 = pr[i] & 0xFFFFu, p2 = pr[i] >> 16;
       double v = kInfF;
-      uint32_t src = p;
-      if (kind >= kM) {  // middle / word end at position >= 2: skip, forward, [loop]
-        v = (sc[p2] + t_skip) + am; src = p2;
-        const double n1 = (sc[p1] + tf) + am;
-        if (n1 < v) { v = n1; src = p1; }
+      uint32_t b = 0;
+      if (kind >= kM) {  // middle / word end at position >= 2: skip, forward, [loop] -- in source order, a later one must be strictly better
+        const Cell c2 = cell(p2[i]), c1 = cell(p1[i]);
+        const double s2 = (c2.score + t_skip) + e, s1 = (c1.score + tf) + e;
+        b = s1 < s2 ? c1.bkp : c2.bkp;
+        v = dmin(s2, s1);
         if (kind == kM) {
-          const double n0 = (sc[p] + t_loop) + am;
-          if (n0 < v) { v = n0; src = p; }
+          const Cell c0 = cell(p);
+          const double s0 = (c0.score + t_loop) + e;
+          b = s0 < v ? c0.bkp : b;
+          v = dmin(v, s0);
         }
-        nb[i] = bk[src];
       } else {
         // entry slots: in-word candidates (forward for position 1, loop unless word end) ...
-        double am_b = am;
         if (kind == kE1 || kind == kE1E) {
-          v = (sc[p1] + tf) + am; src = p1;
-          am_b = am_l[p1];  // boundary candidates are scored with position 0's emission (:136,148-151)
+          const Cell c1 = cell(p1[i]);
+          v = (c1.score + tf) + e;
+          b = c1.bkp;
         }
         if (kind == kE0 || kind == kE1) {
-          const double n0 = (sc[p] + t_loop) + am;
-          if (n0 < v) { v = n0; src = p; }
+          const Cell c0 = cell(p);
+          const double s0 = (c0.score + t_loop) + e;
+          b = s0 < v ? c0.bkp : b;
+          v = dmin(v, s0);
         }
-        // ... and the collapsed word-boundary candidate, placed before or after them by source index
-        const double wp = (type & kTSilWord) ? 0.0 : wp_word;
-        const bool b_skip = (kind == kE1 || kind == kE1E) && !(type & kTFirstSil);
-        const double t_b = b_skip ? ts : tf;
-        const uint32_t cls = ((type & kTSilWord) ? 0u : 2u) + (b_skip ? 1u : 0u);
-        const double n_b = ((m_we + wp) + t_b) + am_b;
-        const bool b_first = ef_cur[cls] < (og[i] >> 16);
-        const bool take_b = b_first ? !(v < n_b) : (n_b < v);
-        const uint32_t in_bkp = bk[src];
-        v = take_b ? n_b : v;
-        nb[i] = take_b ? bkp_new : in_bkp;
-        if (kind == kE0S) {  // one-position word: its dead position-1 slot still feeds best_score (:139,155)
-          const double dead = ((m_we + wp) + ((type & kTFirstSil) ? tf : ts)) + am;
-          my_best = dead < my_best ? dead : my_best;
+        // ... and the collapsed word-boundary candidate, placed before or after them by source index.  It is scored with
+        // position 0's emission (Recognizer.cpp:136,148-151)
+        if (we_in) {  // uniform
+          const double wp = (type & kTSilWord) ? 0.0 : wp_word;
+          const bool b_skip = (kind == kE1 || kind == kE1E) && !(type & kTFirstSil);
+          const double t_b = b_skip ? ts : tf;
+          const uint32_t cls = ((type & kTSilWord) ? 0u : 2u) + (b_skip ? 1u : 0u);
+          const double cb = (m_we + wp) + t_b;  // the same in every lane and for every slot of the class: computed once
+          const double n_b = cb + ((kind == kE1 || kind == kE1E) ? (ROWS ? row_l[st0[i]] : am0[i]) : e);
+          bool take = n_b < v;
+          const bool tie = n_b == v;  // (n_b is finite here)
+          if (__any(tie)) take |= tie && ef_cur[cls] < (og[i] >> 16);  // the boundary source came first: the in-word candidate had to be strictly better
+          b = take ? bkp_new : b;
+          v = dmin(v, n_b);
+          if (kind == kE0S) {  // one-position word: its dead position-1 slot still feeds best_score (:139,155)
+            const double dead = ((m_we + wp) + ((type & kTFirstSil) ? tf : ts)) + e;
+            my_best = dmin(my_best, dead);
+          }
         }
       }
-      const bool real = og[i] != 0xFFFFFFFFu;  // padding lanes inside a type's last chunk
-      v = real ? v : kInfF;
-      nv[i] = v;
-      my_best = v < my_best ? v : my_best;
-      if (kind == kE0S || kind == kE1E || kind == kME) {  // word ends
-        const uint32_t o = og[i] & 0xFFFFu;
-        if (real && (v < my_we || (v == my_we && o < my_we_idx))) { my_we = v; my_we_idx = o; }
-      }
+      if (pad_chunks >> i & 1u) v = og[i] != 0xFFFFFFFFu ? v : kInfF;  // (scalar branch) padding lanes of a type's last chunk
+      nv[i] = v; nb[i] = b;
+      my_best = dmin(my_best, v);
+      if (kind == kE0S || kind == kE1E || kind == kME) my_we = dmin(my_we, v);
     };
     if (uniform_kind) {
-      // All SPT chunks of this wave are of one kind (a wave holds consecutive chunks of the type-sorted net):
-      // one scalar branch, then the SPT slots as straight-line code whose LDS reads and FP64 chains interleave -- per slot
-      // the loop is a dependent chain, and four waves per SIMD do not hide it
+      // All SPT chunks of this wave are of one kind (a wave holds consecutive chunks of the type-sorted net): one scalar
+      // branch, then the SPT slots as straight-line code whose LDS reads and FP64 chains interleave
 #pragma unroll
       for (int i = 0; i < SPT; i++) { nv[i] = kInfF; nb[i] = 0; }
       switch (ty[0] & kKindMask) {
@@ -261,50 +344,42 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
         slot_a(KindR{kind}, type, i);
       }
     }
-    if (neg) *bail = 1;
-    if (tid < 4) ef_nxt[tid] = 0xFFFFFFFFu;
 
-    // ---- B ----------------------------------------------------------------------------------------------
-    my_best = wave_min_dpp(my_best);
-    if (wave_has_we) wave_min_idx_dpp(my_we, my_we_idx);  // (other waves keep +inf / no index)
-    if (lane == 0) { red_best[wave] = my_best; red_we[wave] = my_we; red_idx[wave] = my_we_idx; }
+    // ---- B: block minima through LDS ds_min_f64 cells, fed by one lane per row ------------------------------------
+    my_best = row_min_dpp(my_best);
+    if ((lane & 15u) == 0) atomic_min_f64_lds(&c_best[par], my_best);
+    if (wave_has_we) {
+      my_we = row_min_dpp(my_we);
+      if ((lane & 15u) == 0) atomic_min_f64_lds(&c_we[par], my_we);
+    }
     __syncthreads();
-    if (*bail) {  // workgroup-uniform: hand the utterance to the replay variant
-      if (tid == 0) { atomicOr(&a.out_flags[u], kFlagReplay); a.out_count[u] = 0; }
-      return true;
-    }
-    double best = red_best[lane & (NW - 1)], we = red_we[lane & (NW - 1)];
-    uint32_t we_idx = red_idx[lane & (NW - 1)];
-    if (NW > 1) {  // NW <= 16 partials, replicated in every row of 16 lanes: a row-level reduction is enough
-      static_assert(NW <= 16, "one row of 16 lanes holds all per-wave partials");
-      best = row_min_dpp(best);
-      row_min_idx_dpp(we, we_idx);
-    }
 
-    // ---- C ----------------------------------------------------------------------------------------------
+    // ---- C: prune, publish the word-end minimum --------------------------------------------------------------------
+    const double best = c_best[par], we = c_we[par];
     const double limit = best + thr;
     const bool we_alive = !(we > limit) && we != kInfF;
     m_we = we_alive ? we : kInfF;
-    const double near = m_we + (fabs(m_we) + fabs(wp_word) + fabs(tf) + fabs(ts) + 1.0) * 1e-9;
+    prev_alive = we_alive;
 #pragma unroll
-    for (int i = 0; i < SPT; i++) {  // the stores of all slots first: straight-line
-      const uint32_t p = slot_of(i);
+    for (int i = 0; i < SPT; i++) {
       double v = nv[i];
       if (v > limit) v = kInfF;  // :194-196
       nv[i] = v;
-      sc[p] = v;
-      bk[p] = (uint16_t)nb[i];
-      am_l[p] = am_n[i];
+      sc[slot_of(i)] = v; bk[slot_of(i)] = nb[i];
     }
     if (wave_has_we && we_alive) {  // wave-uniform
+      const double near = m_we + (fabs(m_we) + fabs(wp_word) + fabs(tf) + fabs(ts) + 1.0) * 1e-9;
 #pragma unroll
       for (int i = 0; i < SPT; i++) {
         const uint32_t kind = ty[i] & kKindMask;
         if (kind == kE0S || kind == kE1E || kind == kME) {
           const double v = nv[i];
-          if (v <= near) {
-            const uint32_t p = slot_of(i), o = og[i] & 0xFFFFu;
-            if (o == we_idx) { a.tb_score[tb0 + t] = v; a.tb_word[tb0 + t] = (uint16_t)p; a.tb_bkp[tb0 + t] = (uint16_t)nb[i]; }
+          if (v <= near) {  // about one lane of the block
+            const uint32_t o = og[i] & 0xFFFFu;
+            if (v == m_we) {  // traceback[t] = the FIRST minimal surviving word end (:199-205): settled by the atomic, written next frame
+              atomicMin(&c_widx[par], o);
+              pend = true; pend_o = o; pend_p = slot_of(i); pend_b = nb[i]; pend_v = v;
+            }
             if (v + 0.0 + tf == m_we + 0.0 + tf) atomicMin(&ef_nxt[0], o);
             if (v + 0.0 + ts == m_we + 0.0 + ts) atomicMin(&ef_nxt[1], o);
             if (v + wp_word + tf == m_we + wp_word + tf) atomicMin(&ef_nxt[2], o);
@@ -313,25 +388,29 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
         }
       }
     }
-    if (!we_alive && tid == 0) { a.tb_score[tb0 + t] = kInfF; a.tb_word[tb0 + t] = 0xFFFFu; a.tb_bkp[tb0 + t] = 0; }
+    if (ROWS) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of the next row have landed; the barrier publishes them
     __syncthreads();
-    return false;
-  };
+  }
+  if (T > 0) flush_pending(T);
 
-  for (uint32_t t = 1; t <= T; t++)
-    if (frame(t)) return;
-
-  // ---- traceback (Recognizer.cpp:222-231; guarded walk: traceback.h) -------------------------------------------
+  // the fast path's premise failed somewhere (a negative or NaN emission cost): hand the utterance to the replay variant
+  if (bad) *s_bad = 1;
   __threadfence();
   __syncthreads();
-  bool bad = false;
+  if (*s_bad) {  // workgroup-uniform
+    if (tid == 0) { atomicOr(&a.out_flags[u], kFlagReplay); a.out_count[u] = 0; }
+    return;
+  }
+
+  // ---- traceback (Recognizer.cpp:222-231; guarded walk: traceback.h) -------------------------------------------
+  bool corrupt = false;
   for (uint32_t t = 1 + tid; t <= T; t += NT) {  // winning slot -> word
     const uint32_t sl = __hip_atomic_load(&a.tb_word[tb0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint16_t w = 0;  // 0xFFFF: no surviving word end -> Book(inf, 0, 0), :118,191
-    if (sl != 0xFFFFu) { if (sl < net.n_slots) w = (uint16_t)net.word[sl]; else bad = true; }
+    if (sl != 0xFFFFu) { if (sl < net.n_slots) w = (uint16_t)net.word[sl]; else corrupt = true; }
     a.tb_word[tb0 + t] = w;
   }
-  if (bad) atomicOr(&a.out_flags[u], kFlagCorrupt);
+  if (corrupt) atomicOr(&a.out_flags[u], kFlagCorrupt);
   __threadfence();
   __syncthreads();
   if (tid == 0) {
@@ -345,7 +424,11 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
   }
 }
 
-static size_t fast_smem(uint32_t PP) { return (size_t)PP * 16 + 16 * 8 * 2 + 16 * 4 + 12 * 4 + (size_t)PP * 2 + 16; }
+static size_t fast_smem(uint32_t PP, uint32_t ld, bool rows) {
+  const size_t base = (fast_smem_base(PP) + 1023u) & ~(size_t)1023u;
+  return rows ? base + 2 * (((size_t)ld * 8 + 1023u) & ~(size_t)1023u) : base;
+}
+static constexpr size_t kLdsPerWorkgroup = 160 * 1024;
 
 hipError_t launch_decode_fast(const DecodeArgs& a, hipStream_t stream) {
   if (a.n_utts == 0) return hipSuccess;
@@ -353,10 +436,13 @@ hipError_t launch_decode_fast(const DecodeArgs& a, hipStream_t stream) {
   const dim3 grid(a.n_utts);
 #define SR_LAUNCH(NT, SPT)                                                                                              \
   do {                                                                                                                  \
-    const size_t smem = fast_smem((NT) * (SPT));                                                                        \
-    hipError_t e = hipFuncSetAttribute((const void*)decode_fast_kernel<NT, SPT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    const bool rows = fast_smem((NT) * (SPT), a.ld, true) <= kLdsPerWorkgroup;                                          \
+    const size_t smem = fast_smem((NT) * (SPT), a.ld, rows);                                                            \
+    const void* fn = rows ? (const void*)decode_fast_kernel<NT, SPT, true> : (const void*)decode_fast_kernel<NT, SPT, false>; \
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                      \
     if (e != hipSuccess) return e;                                                                                      \
-    hipLaunchKernelGGL((decode_fast_kernel<NT, SPT>), grid, dim3(NT), smem, stream, a);                                 \
+    if (rows) hipLaunchKernelGGL((decode_fast_kernel<NT, SPT, true>), grid, dim3(NT), smem, stream, a);                 \
+    else hipLaunchKernelGGL((decode_fast_kernel<NT, SPT, false>), grid, dim3(NT), smem, stream, a);                     \
     return hipGetLastError();                                                                                           \
   } while (0)
   if (a.n_utts <= 256) {

@@ -7,15 +7,36 @@ usage: python3 tools/summarize_profile.py gpurun_out/profile_TAG  -> gpurun_out/
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
+import subprocess
 import sys
 
 root = sys.argv[1]
+
+
+def kernel_sources_sha16():
+    """Identity of the kernels the counters belong to: sha256 over the device sources (sorted by name), first 16 hex digits.
+    bench.py prints `traffic` only while this still matches the tree it runs from."""
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "speechrecognition_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 short = lambda n: n.split("(")[0].replace("void ", "").replace("srgpu::", "")
 out = {"source": "tools/profile_bench.sh: rocprofv3 --kernel-trace --stats (3 timed steps + 1 warm-up) and one "
                  "rocprofv3 --pmc pass per counter group (1 step + 1 warm-up) of python3 bench.py, MI355X",
-       "kernels": {}}
+       "kernel_sources_sha16": kernel_sources_sha16(), "kernels": {}}
+try:
+    out["git_head"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True, stderr=subprocess.DEVNULL,
+                                              cwd=os.path.dirname(os.path.abspath(__file__))).strip()
+except (OSError, subprocess.CalledProcessError):
+    pass  # the GPU box has no .git: the commit is added when the summary is copied into profiles/
 try:
     out["bench_line_under_profiler"] = json.loads(open(os.path.join(root, "bench_under_profiler.json")).read())
     cfg = out["bench_line_under_profiler"]["config"]
