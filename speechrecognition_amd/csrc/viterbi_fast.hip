@@ -24,7 +24,7 @@ namespace srgpu {
 
 static constexpr double kInfF = __builtin_huge_val();
 // LDS of decode_fast_kernel before the row buffers: scores, the minima cells, first-index cells, flag, back pointers
-__host__ __device__ constexpr size_t fast_smem_base(uint32_t PP) { return (size_t)PP * 8 + 4 * 8 + 2 * 4 + 8 * 4 + 2 * 4 + (size_t)PP * 4 + 16; }
+__host__ __device__ constexpr size_t fast_smem_base(uint32_t PP) { return (size_t)PP * 16 + 4 * 8 + 2 * 4 + 8 * 4 + 2 * 4 + 16; }
 
 // ---- DPP helpers --------------------------------------------------------------------------------------
 template <int CTRL, int ROW_MASK>
@@ -103,10 +103,12 @@ static constexpr uint32_t kTSilState = 8u, kTSilWord = 16u, kTFirstSil = 32u;
 template <uint32_t K> struct KindC { __device__ constexpr operator uint32_t() const { return K; } };  // a slot kind known at compile time
 struct KindR { uint32_t v; __device__ operator uint32_t() const { return v; } };                          // ... or only at run time
 
-// One hypothesis in LDS: its score and its back pointer, in two arrays (consecutive lanes -> consecutive words: conflict-free;
-// a 16-byte {score, bkp} cell was tried first and cost 4e8 bank-conflict cycles per launch, the compiler splits it into a b64
-// and a b32 access at a 16-byte stride).  Round 2 also kept a copy of the frame's emission costs there.
+// One hypothesis in LDS: a 16-byte cell {score, back pointer, -} read and written as ONE 128-bit access -- consecutive lanes,
+// consecutive cells: conflict-free, one address register per source.  (Left to the compiler a struct of that shape became a b64
+// and a b32 access at a 16-byte stride: 4e8 bank-conflict cycles per launch; two separate arrays were conflict-free but
+// doubled the LDS instructions and the hoisted address registers: 412 bytes of scratch in the frame loop.)
 struct Cell { double score; uint32_t bkp; };
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // Round 3 ("instruction diet"): the frame loop was 260 vector instructions per wave and frame for 4 slots per
 // lane; this version issues ~90.  What went:
@@ -134,17 +136,22 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr uint32_t PP = NT * SPT;
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  double* sc = reinterpret_cast<double*>(smem);                     // [PP] hypothesis scores
-  double* c_best = sc + PP;                                         // [2] block minimum of the frame's new scores, by frame parity
+  // smem: [PP] hypothesis cells of 16 bytes, then:
+  double* c_best = reinterpret_cast<double*>(smem + (size_t)PP * 16);  // [2] block minimum of the frame's new scores, by frame parity
   double* c_we = c_best + 2;                                        // [2] minimum over word-end slots
   uint32_t* c_widx = reinterpret_cast<uint32_t*>(c_we + 2);         // [2] first ORIGINAL index among the minimal word ends
   uint32_t* e_first = c_widx + 2;                                   // [2][4] first word-end original index per class, by frame parity
   uint32_t* s_bad = e_first + 8;                                    // [1] some emission cost was negative or NaN
-  uint32_t* bk = s_bad + 2;                                         // [PP] back pointers
   // ROWS: two row buffers (frame parity) behind the hypotheses, 1 KB granular (one LDS-DMA piece = 64 lanes x 16 bytes)
   const uint32_t row_bytes = a.ld * 8u, row_pad = (row_bytes + 1023u) & ~1023u;
   unsigned char* rows_lds = smem + ((fast_smem_base(PP) + 1023u) & ~(size_t)1023u);
-  auto cell = [&](uint32_t p) -> Cell { return Cell{sc[p], bk[p]}; };
+  auto cell = [&](uint32_t byte_off) -> Cell {  // one ds_read_b128
+    const u32x4 r = *reinterpret_cast<const u32x4*>(smem + byte_off);
+    return Cell{__hiloint2double((int)r.y, (int)r.x), r.z};
+  };
+  auto put_cell = [&](uint32_t byte_off, double v, uint32_t b) {  // one ds_write_b128
+    *reinterpret_cast<u32x4*>(smem + byte_off) = u32x4{(uint32_t)__double2loint(v), (uint32_t)__double2hiint(v), b, 0u};
+  };
 
   const FastNet& net = a.fast;
   const uint32_t u = a.utt_order ? a.utt_order[a.utt_first + blockIdx.x] : a.utt_first + blockIdx.x;
@@ -167,13 +174,13 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
     const bool in = p < net.n_slots;
     st[i] = in ? net.state[p] : 0u;      // padding slots read state 0: a valid address, value unused
     const uint32_t pr = in ? net.pred[p] : (p | (p << 16));
-    p1[i] = pr & 0xFFFFu; p2[i] = pr >> 16;
+    p1[i] = (pr & 0xFFFFu) * 16u; p2[i] = (pr >> 16) * 16u;  // byte offsets of the predecessors' cells
     og[i] = in ? net.orig[p] : 0xFFFFFFFFu;
     ty[i] = __builtin_amdgcn_readfirstlane(in ? net.chunk_type[p >> 6] : kPad);  // one type per 64-slot chunk
     const uint32_t kind = ty[i] & kKindMask;
-    st0[i] = (kind == kE1 || kind == kE1E) ? net.state[p1[i]] : st[i];            // emission state of the word's position 0
+    st0[i] = (kind == kE1 || kind == kE1E) ? net.state[pr & 0xFFFFu] : st[i];            // emission state of the word's position 0
     if (__any(og[i] == 0xFFFFFFFFu)) pad_chunks |= 1u << i;
-    sc[p] = kInfF; bk[p] = 0u;
+    put_cell(p * 16u, kInfF, 0u);
   }
   bool uniform_kind = true;  // wave-uniform: all of this wave's chunks have the same type word
 #pragma unroll
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
   const bool init_is_end = net.init_is_end;
   double m_we = init_is_end ? 0.0 : kInfF;  // minimum over the word ends that survived the previous frame (uniform)
   if (tid == 0) {
-    sc[net.init_slot] = 0.0;  // initial hypothesis: word 0, position 0, score 0 (Recognizer.cpp:120)
+    put_cell(net.init_slot * 16u, 0.0, 0u);  // initial hypothesis: word 0, position 0, score 0 (Recognizer.cpp:120)
     a.tb_score[tb0] = 0.0; a.tb_word[tb0] = 0; a.tb_bkp[tb0] = 0;
   }
   if (tid < 4 && init_is_end) e_first[4 + tid] = 0;
@@ -259,77 +266,91 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
     if (tid == 4) { c_best[par ^ 1] = kInfF; c_we[par ^ 1] = kInfF; c_widx[par] = 0xFFFFFFFFu; }
 
     // ---- A: candidates of every slot --------------------------------------------------------------------------
+    // Staged: every LDS read of the wave's SPT slots is issued before the first value is used, the arithmetic of all slots
+    // follows as one block, and the two rare cases (an exact tie between the boundary candidate and an in-word candidate;
+    // padding lanes) are patched afterwards -- a per-slot `if (__any(...))` in the middle splits the block, and then each slot
+    // pays its own LDS round trip (phase A of the mixed-kind waves was 3 000 cycles of 7 900 per frame that way,
+    // profiles/r3_decoder_diet.txt).
     double nv[SPT];
     uint32_t nb[SPT];
+    bool tie[SPT];
+    uint64_t tie_any = 0;
     double my_best = kInfF, my_we = kInfF;
-    const bool we_in = m_we != kInfF;  // uniform: a word end survived the previous frame -- else there is no boundary candidate
-    // one slot; `kind` is wave-uniform -- a run-time scalar (KindR) or a compile-time constant (KindC)
-    auto slot_a = [&](const auto kind, const uint32_t type, const int i) __attribute__((always_inline)) {
-      const uint32_t p = slot_of(i);
-      const double e = ROWS ? row_l[st[i]] : am[i];
+    const bool we_in = m_we != kInfF;  // uniform: a word end survived the previous frame -- else every boundary candidate is +inf
+    struct In { Cell c0, c1, c2; double e, e0; };  // what a slot reads: its sources' cells, its emission cost and position 0's
+    // `kind` is wave-uniform -- a run-time scalar (KindR) or a compile-time constant (KindC)
+    auto load_slot = [&](const auto kind, const int i, In& in) __attribute__((always_inline)) {
+      const bool pos1 = kind == kE1 || kind == kE1E;
+      in.e = ROWS ? row_l[st[i]] : am[i];
+      in.e0 = pos1 ? (ROWS ? row_l[st0[i]] : am0[i]) : in.e;
+      if (kind >= kM) in.c2 = cell(p2[i]);
+      if (kind >= kM || pos1) in.c1 = cell(p1[i]);
+      if (kind == kM || kind == kE0 || kind == kE1) in.c0 = cell(slot_of(i) * 16u);
+    };
+    auto compute_slot = [&](const auto kind, const uint32_t type, const int i, const In& in) __attribute__((always_inline)) {
+      const double e = in.e;
       bad |= __ballot(!(e >= 0.0));
       const bool sil = type & kTSilState;
       const double t_loop = sil ? tf : tl, t_skip = sil ? tf : ts;  // scalars: TdpModel.cpp:19-29 keyed on the destination
       double v = kInfF;
       uint32_t b = 0;
+      tie[i] = false;
       if (kind >= kM) {  // middle / word end at position >= 2: skip, forward, [loop] -- in source order, a later one must be strictly better
-        const Cell c2 = cell(p2[i]), c1 = cell(p1[i]);
-        const double s2 = (c2.score + t_skip) + e, s1 = (c1.score + tf) + e;
-        b = s1 < s2 ? c1.bkp : c2.bkp;
+        const double s2 = (in.c2.score + t_skip) + e, s1 = (in.c1.score + tf) + e;
+        b = s1 < s2 ? in.c1.bkp : in.c2.bkp;
         v = dmin(s2, s1);
         if (kind == kM) {
-          const Cell c0 = cell(p);
-          const double s0 = (c0.score + t_loop) + e;
-          b = s0 < v ? c0.bkp : b;
+          const double s0 = (in.c0.score + t_loop) + e;
+          b = s0 < v ? in.c0.bkp : b;
           v = dmin(v, s0);
         }
       } else {
         // entry slots: in-word candidates (forward for position 1, loop unless word end) ...
         if (kind == kE1 || kind == kE1E) {
-          const Cell c1 = cell(p1[i]);
-          v = (c1.score + tf) + e;
-          b = c1.bkp;
+          v = (in.c1.score + tf) + e;
+          b = in.c1.bkp;
         }
         if (kind == kE0 || kind == kE1) {
-          const Cell c0 = cell(p);
-          const double s0 = (c0.score + t_loop) + e;
-          b = s0 < v ? c0.bkp : b;
+          const double s0 = (in.c0.score + t_loop) + e;
+          b = s0 < v ? in.c0.bkp : b;
           v = dmin(v, s0);
         }
-        // ... and the collapsed word-boundary candidate, placed before or after them by source index.  It is scored with
-        // position 0's emission (Recognizer.cpp:136,148-151)
-        if (we_in) {  // uniform
-          const double wp = (type & kTSilWord) ? 0.0 : wp_word;
-          const bool b_skip = (kind == kE1 || kind == kE1E) && !(type & kTFirstSil);
-          const double t_b = b_skip ? ts : tf;
-          const uint32_t cls = ((type & kTSilWord) ? 0u : 2u) + (b_skip ? 1u : 0u);
-          const double cb = (m_we + wp) + t_b;  // the same in every lane and for every slot of the class: computed once
-          const double n_b = cb + ((kind == kE1 || kind == kE1E) ? (ROWS ? row_l[st0[i]] : am0[i]) : e);
-          bool take = n_b < v;
-          const bool tie = n_b == v;  // (n_b is finite here)
-          if (__any(tie)) take |= tie && ef_cur[cls] < (og[i] >> 16);  // the boundary source came first: the in-word candidate had to be strictly better
-          b = take ? bkp_new : b;
-          v = dmin(v, n_b);
-          if (kind == kE0S) {  // one-position word: its dead position-1 slot still feeds best_score (:139,155)
-            const double dead = ((m_we + wp) + ((type & kTFirstSil) ? tf : ts)) + e;
-            my_best = dmin(my_best, dead);
-          }
+        // ... and the collapsed word-boundary candidate (+inf while no word end is alive), placed before or after them by source
+        // index: after, unless the patch below finds a tie and an earlier word end.  It is scored with position 0's emission
+        // (Recognizer.cpp:136,148-151)
+        const double wp = (type & kTSilWord) ? 0.0 : wp_word;
+        const bool b_skip = (kind == kE1 || kind == kE1E) && !(type & kTFirstSil);
+        const double cb = (m_we + wp) + (b_skip ? ts : tf);  // the same in every lane and for every slot of the class
+        const double n_b = cb + in.e0;
+        tie[i] = we_in && n_b == v;
+        tie_any |= __ballot(tie[i]);
+        b = n_b < v ? bkp_new : b;
+        v = dmin(v, n_b);
+        if (kind == kE0S) {  // one-position word: its dead position-1 slot still feeds best_score (:139,155)
+          const double dead = ((m_we + wp) + ((type & kTFirstSil) ? tf : ts)) + e;
+          my_best = dmin(my_best, dead);
         }
       }
-      if (pad_chunks >> i & 1u) v = og[i] != 0xFFFFFFFFu ? v : kInfF;  // (scalar branch) padding lanes of a type's last chunk
       nv[i] = v; nb[i] = b;
-      my_best = dmin(my_best, v);
-      if (kind == kE0S || kind == kE1E || kind == kME) my_we = dmin(my_we, v);
     };
-    if (uniform_kind) {
-      // All SPT chunks of this wave are of one kind (a wave holds consecutive chunks of the type-sorted net): one scalar
-      // branch, then the SPT slots as straight-line code whose LDS reads and FP64 chains interleave
 #pragma unroll
-      for (int i = 0; i < SPT; i++) { nv[i] = kInfF; nb[i] = 0; }
+    for (int i = 0; i < SPT; i++) { nv[i] = kInfF; nb[i] = 0; tie[i] = false; }
+    // Most waves hold ONE type (a wave owns consecutive chunks of the type-sorted net): the code specialised for that kind,
+    // two slots at a time -- their reads in flight together, then their arithmetic (all SPT at once: 40 registers more than a
+    // 1024-thread workgroup has, 412 bytes of scratch in the frame loop, 17 ms).  The few waves that straddle a type boundary
+    // -- they set the pace at the barrier -- take the kind as a run-time scalar and read every source a slot of any kind could
+    // have (predecessor ids of a slot without predecessors point at the slot itself), so that their reads are not split by
+    // branches either.
+    constexpr int G = SPT >= 2 ? 2 : 1;
+    if (uniform_kind) {
       switch (ty[0] & kKindMask) {
-#define SR_KIND_CASE(K)                                                   \
-        case K:                                                           \
-          _Pragma("unroll") for (int i = 0; i < SPT; i++) slot_a(KindC<K>{}, ty[0], i); \
+#define SR_KIND_CASE(K)                                                                                   \
+        case K:                                                                                           \
+          _Pragma("unroll") for (int h = 0; h < SPT; h += G) {                                            \
+            In in[G];                                                                                     \
+            _Pragma("unroll") for (int i = h; i < h + G; i++) load_slot(KindC<K>{}, i, in[i - h]);        \
+            _Pragma("unroll") for (int i = h; i < h + G; i++) compute_slot(KindC<K>{}, ty[0], i, in[i - h]); \
+          }                                                                                               \
           break;
         SR_KIND_CASE(kE0) SR_KIND_CASE(kE0S) SR_KIND_CASE(kE1) SR_KIND_CASE(kE1E) SR_KIND_CASE(kM) SR_KIND_CASE(kME)
 #undef SR_KIND_CASE
@@ -337,12 +358,48 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
       }
     } else {
 #pragma unroll
+      for (int h = 0; h < SPT; h += G) {
+        In in[G];
+#pragma unroll
+        for (int i = h; i < h + G; i++) {  // every source a slot of ANY kind could read, unconditionally: no branch, no wait in here
+          in[i - h].e = ROWS ? row_l[st[i]] : am[i];
+          const uint32_t k_ = ty[i] & kKindMask;
+          in[i - h].e0 = ROWS ? row_l[st0[i]] : ((k_ == kE1 || k_ == kE1E) ? am0[i] : am[i]);  // (st0 = st unless position 1)
+          in[i - h].c2 = cell(p2[i]);
+          in[i - h].c1 = cell(p1[i]);
+          in[i - h].c0 = cell(slot_of(i) * 16u);
+        }
+#pragma unroll
+        for (int i = h; i < h + G; i++) {
+          switch (ty[i] & kKindMask) {  // wave-uniform; the arithmetic is the specialised one (a run-time kind gets if-converted
+                                        // into all kinds' arithmetic plus selects: three times the instructions)
+#define SR_KIND_CASE(K) case K: compute_slot(KindC<K>{}, ty[i], i, in[i - h]); break;
+            SR_KIND_CASE(kE0) SR_KIND_CASE(kE0S) SR_KIND_CASE(kE1) SR_KIND_CASE(kE1E) SR_KIND_CASE(kM) SR_KIND_CASE(kME)
+#undef SR_KIND_CASE
+            default: break;  // kPad
+          }
+        }
+      }
+    }
+    if (tie_any) {  // rare: the boundary source came first where the first minimal word end of the class precedes the slot's word
+#pragma unroll
       for (int i = 0; i < SPT; i++) {
         const uint32_t type = ty[i], kind = type & kKindMask;
-        nv[i] = kInfF; nb[i] = 0;
-        if (kind == kPad) continue;  // wave-uniform
-        slot_a(KindR{kind}, type, i);
+        const bool b_skip = (kind == kE1 || kind == kE1E) && !(type & kTFirstSil);
+        const uint32_t cls = ((type & kTSilWord) ? 0u : 2u) + (b_skip ? 1u : 0u);
+        if (tie[i] && ef_cur[cls] < (og[i] >> 16)) nb[i] = bkp_new;  // the in-word candidate had to be strictly better
       }
+    }
+    if (pad_chunks) {  // padding lanes of a type's last chunk hold nothing
+#pragma unroll
+      for (int i = 0; i < SPT; i++)
+        if (pad_chunks >> i & 1u) nv[i] = og[i] != 0xFFFFFFFFu ? nv[i] : kInfF;
+    }
+#pragma unroll
+    for (int i = 0; i < SPT; i++) {
+      const uint32_t kind = ty[i] & kKindMask;
+      my_best = dmin(my_best, nv[i]);
+      if (kind == kE0S || kind == kE1E || kind == kME) my_we = dmin(my_we, nv[i]);
     }
 
     // ---- B: block minima through LDS ds_min_f64 cells, fed by one lane per row ------------------------------------
@@ -365,16 +422,23 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
       double v = nv[i];
       if (v > limit) v = kInfF;  // :194-196
       nv[i] = v;
-      sc[slot_of(i)] = v; bk[slot_of(i)] = nb[i];
+      put_cell(slot_of(i) * 16u, v, nb[i]);
     }
     if (wave_has_we && we_alive) {  // wave-uniform
       const double near = m_we + (fabs(m_we) + fabs(wp_word) + fabs(tf) + fabs(ts) + 1.0) * 1e-9;
+      bool nr[SPT];
+      uint64_t any_near = 0;
 #pragma unroll
       for (int i = 0; i < SPT; i++) {
         const uint32_t kind = ty[i] & kKindMask;
-        if (kind == kE0S || kind == kE1E || kind == kME) {
-          const double v = nv[i];
-          if (v <= near) {  // about one lane of the block
+        nr[i] = (kind == kE0S || kind == kE1E || kind == kME) && nv[i] <= near;
+        any_near |= __ballot(nr[i]);
+      }
+      if (any_near) {  // the wave that holds the minimum (about one lane of the block)
+#pragma unroll
+        for (int i = 0; i < SPT; i++) {
+          if (nr[i]) {
+            const double v = nv[i];
             const uint32_t o = og[i] & 0xFFFFu;
             if (v == m_we) {  // traceback[t] = the FIRST minimal surviving word end (:199-205): settled by the atomic, written next frame
               atomicMin(&c_widx[par], o);

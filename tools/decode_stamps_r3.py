@@ -18,10 +18,10 @@ for _ in range(2):
     tbs, tbw, tbb = np.zeros(n, np.float64), np.zeros(n, np.uint16), np.zeros(n, np.uint16)
     sp = capi.SearchParams(200.0, 10.0, capi.GMM_MFMA, 0)
     rc = capi.lib().sr_recognize_corpus(m.h, c.h, lexh.h, C.byref(sp), words.ctypes.data, woff.ctypes.data, tbs.ctypes.data, tbw.ctypes.data, tbb.ctypes.data)
-names = ["top: am copy + gather issue", "flush + resets", "phase A", "B reduce + atomics", "barrier 1", "C: cell read", "C: prune/store/we", "barrier 2"]
-for wi, wv in enumerate((0, 5, 10, 15)):
-    sums = np.zeros(8); frames = 0
+names = ["top", "flush", "A g0 loads(wait)", "A g0 compute", "A g1 loads(wait)", "A g1 compute", "A rest (uniform waves: all of A)", "B", "barrier 1", "C read", "C", "barrier 2"]
+for wi, wv in enumerate((0, 7, 10, 15)):
+    sums = np.zeros(12); frames = 0
     for u in range(len(off) - 1):
         b = int(off[u]) + u
-        sums += tbs[b + 1 + 8 * wi: b + 9 + 8 * wi]; frames += int(off[u + 1] - off[u])
+        sums += tbs[b + 1 + 12 * wi: b + 13 + 12 * wi]; frames += int(off[u + 1] - off[u])
     print(f"wave {wv}: cycles per frame:", {n: int(round(v / frames)) for n, v in zip(names, sums)}, "total", int(round(sums.sum() / frames)))
