@@ -94,7 +94,7 @@ SR_API int sr_model_info(const sr_model* m, uint32_t* dim, uint32_t* n_states, u
  * The host buffer is borrowed for the duration of the call only. */
 SR_API int sr_corpus_upload(sr_model* m, const float* feats, const uint64_t* frame_off, uint32_t n_utts, sr_corpus** out);
 /* The frame-batch feeder proper: like sr_corpus_upload, but it returns as soon as the handle exists.  A feeder thread copies
- * the host buffer in 8 MiB pieces through two pinned staging buffers on the corpus' own copy stream; the compute entry
+ * the host buffer in 2 MiB pieces through two pinned staging buffers on the corpus' own copy stream; the compute entry
  * points below wait -- on the device, per score chunk -- only for the pieces a chunk needs, so the transfer of later
  * utterances overlaps the scoring of earlier ones.  The host buffer is borrowed until sr_corpus_wait() has returned (or
  * the corpus has been destroyed); sr_corpus_wait returns the feeder's status.  sr_recognize_batch feeds this way. */

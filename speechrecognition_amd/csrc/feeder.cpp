@@ -3,7 +3,7 @@
 // The reference hands its recogniser one contiguous float buffer per corpus (Corpus::read, sietill/Corpus.cpp:89-111) and
 // spreads the segments over host threads (`#pragma omp parallel for`, Recognizer.cpp:46-47).  Here:
 //
-//   * sr_corpus_upload_async: the buffer goes to the device in 8 MiB pieces through two PINNED staging buffers -- a feeder
+//   * sr_corpus_upload_async: the buffer goes to the device in 2 MiB pieces through two PINNED staging buffers -- a feeder
 //     thread fills one while the copy engine drains the other on the corpus' own stream -- and the compute entry points
 //     wait, per score chunk and on the device, only for the pieces that chunk needs (srhost::corpus_ready): the transfer of
 //     later utterances overlaps the scoring of earlier ones.  A piece list instead of one pointer lets the multi-device
@@ -22,7 +22,8 @@ using srhost::fail;
 using srhost::guarded;
 
 namespace {
-constexpr size_t kPieceBytes = 8u << 20;  // per staging buffer; 47 MB of features = 6 pieces
+constexpr size_t kPieceBytes = 2u << 20;  // per staging buffer; 47 MB of features = 23 pieces (8 MiB pieces made the first scoring
+                                          // launch wait 1.1 ms for its data: profiles/r3_batch_boundary.txt)
 struct Segment { const float* src; uint64_t n_floats; };  // host memory, copied in order to consecutive device addresses
 }  // namespace
 
@@ -135,6 +136,7 @@ int corpus_from_segments(sr_model* m, std::vector<Segment> segments, const uint6
   std::unique_ptr<sr_corpus, int (*)(sr_corpus*)> own(c, sr_corpus_destroy);
   c->model = m; c->n_utts = n_utts; c->n_frames = F;
   c->frame_off.assign(frame_off, frame_off + n_utts + 1);
+  srhost::corpus_adopt_spare(c);
   if ((e = c->feats.ensure((size_t)total + 64)) != hipSuccess || (e = c->d_frame_off.upload(frame_off, n_utts + 1)) != hipSuccess)
     return fail(SR_EHIP, "corpus upload: %s", hipGetErrorString(e));
   if (total == 0) { *out = own.release(); return SR_OK; }
@@ -144,7 +146,7 @@ int corpus_from_segments(sr_model* m, std::vector<Segment> segments, const uint6
   fd->piece_floats = kPieceBytes / sizeof(float);
   fd->n_pieces = (uint32_t)((total + fd->piece_floats - 1) / fd->piece_floats);
   fd->done.assign(fd->n_pieces, nullptr);
-  // the model keeps one set of feeder resources (copy stream, two pinned 8 MiB buffers); a second upload that overlaps the
+  // the model keeps one set of feeder resources (copy stream, two pinned 2 MiB buffers); a second upload that overlaps the
   // first gets its own
   bool expected = false;
   if (m->staging_busy.compare_exchange_strong(expected, true)) {

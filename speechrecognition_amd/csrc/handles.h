@@ -46,6 +46,7 @@ struct DevBuf {
     return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
   }
   void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  void swap(DevBuf& o) { T* tp = p; p = o.p; o.p = tp; size_t tn = n; n = o.n; o.n = tn; }
   // handles own their buffers: whatever a destroy function does not release by name goes with the object
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
@@ -58,6 +59,16 @@ struct EventPair { hipEvent_t a, b; int kind; };  // kind 0 = gmm, 1 = search, 2
 
 struct sr_feeder;  // feeder.cpp: the asynchronous upload of a corpus
 
+
+// The device buffers of a destroyed corpus that its model keeps for the next one (sr_recognize_batch creates and destroys a corpus
+// per call: nine hipMalloc / hipFree pairs, about a millisecond of the 1.5 ms a boundary step used to lose against a resident one)
+struct CorpusSpare {
+  DevBuf<float> feats;
+  DevBuf<uint64_t> d_frame_off;
+  DevBuf<uint32_t> utt_order, out_words, out_count, out_flags;
+  DevBuf<double> tb_score;
+  DevBuf<uint16_t> tb_word, tb_bkp;
+};
 
 struct sr_model {
   int device = 0;
@@ -96,6 +107,8 @@ struct sr_model {
   float* staging[2] = {nullptr, nullptr};
   hipEvent_t staging_free[2] = {nullptr, nullptr};
   std::atomic<bool> staging_busy{false};
+  std::mutex spare_mu;
+  std::unique_ptr<CorpusSpare> spare;  // of the last corpus destroyed while none was kept
   // streams / workspace
   hipStream_t s_gmm = nullptr, s_search = nullptr;
   DevBuf<double> scores[2];
@@ -178,4 +191,7 @@ int finalize_accumulated(sr_model* m, sr_corpus* c, int pooling, int max_approx,
 int corpus_ready(sr_corpus* c, uint64_t f0, uint64_t f1, hipStream_t stream);
 bool corpus_upload_in_flight(const sr_corpus* c);
 void feeder_join(sr_corpus* c);  // blocks until the feeder thread (if any) has finished, frees its staging buffers
+// (srgpu_api.cpp) a new corpus takes over the buffers its model kept from the last destroyed one / a dying corpus leaves them
+void corpus_adopt_spare(sr_corpus* c);
+void corpus_donate_spare(sr_corpus* c);
 }  // namespace srhost

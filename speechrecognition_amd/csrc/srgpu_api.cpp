@@ -482,15 +482,17 @@ int ensure_utt_order(sr_model* m, sr_corpus* c, const std::vector<Chunk>& chunks
 }
 
 // Scores frames [f0, f1) of the corpus into `table` (row 0 = frame f0).  While the feeder is still copying
-// (sr_corpus_upload_async) the range is scored in three launches -- the first sixth, up to the half, the rest -- each
+// (sr_corpus_upload_async) the range is scored in four launches -- the first 1/24, up to the sixth, up to the half, the rest -- each
 // waiting on the device only for its own pieces: scoring starts ~1 ms into the transfer and the rest of it hides behind
 // the kernels (the feeder delivers 5-10 GB/s, scoring consumes 2 GB/s of features).  The search that follows sees one table.
 int score_chunk(sr_model* m, sr_corpus* c, uint64_t f0, uint64_t f1, int gmm_kernel, double* table) {
   const uint64_t n = f1 - f0;
-  uint64_t cuts[3] = {f1, f1, f1};
+  uint64_t cuts[4] = {f1, f1, f1, f1};
   int n_cuts = 1;
-  if (srhost::corpus_upload_in_flight(c) && n >= 6 * 4096) { cuts[0] = f0 + n / 6; cuts[1] = f0 + n / 2; n_cuts = 3; }
-  int rc = reserve_scoring(m, gmm_kernel, n_cuts == 3 ? n - n / 2 : n);
+  // (the first launch is what the transfer cannot hide behind: 1/24 of the chunk = 2 MB of configs[2]'s features, 0.3 ms of
+  // staging copy + PCIe instead of the 1.1 ms the first sixth took)
+  if (srhost::corpus_upload_in_flight(c) && n >= 24 * 2048) { cuts[0] = f0 + n / 24; cuts[1] = f0 + n / 6; cuts[2] = f0 + n / 2; n_cuts = 4; }
+  int rc = reserve_scoring(m, gmm_kernel, n_cuts == 4 ? n - n / 2 : n);
   if (rc) return rc;
   uint64_t a = f0;
   for (int i = 0; i < n_cuts; i++) {
@@ -508,6 +510,31 @@ int ensure_score_ws(sr_model* m, const std::vector<Chunk>& chunks) {
   for (int i = 0; i < nbuf; i++) HIP_TRY(m->scores[i].ensure((size_t)mx * m->ld));
   return SR_OK;
 }
+
+}  // namespace
+namespace srhost {
+static void swap_spare(sr_corpus* c, CorpusSpare& sp) {
+  c->feats.swap(sp.feats); c->d_frame_off.swap(sp.d_frame_off); c->utt_order.swap(sp.utt_order); c->out_words.swap(sp.out_words);
+  c->out_count.swap(sp.out_count); c->out_flags.swap(sp.out_flags); c->tb_score.swap(sp.tb_score); c->tb_word.swap(sp.tb_word);
+  c->tb_bkp.swap(sp.tb_bkp);
+}
+void corpus_adopt_spare(sr_corpus* c) {
+  sr_model* m = c->model;
+  std::unique_ptr<CorpusSpare> sp;
+  { std::lock_guard<std::mutex> lk(m->spare_mu); sp = std::move(m->spare); }
+  if (sp) swap_spare(c, *sp);  // (whatever the new corpus held -- nothing -- goes away with sp)
+  c->order_chunk_frames = 0;   // the launch order is rebuilt for the new utterances
+}
+void corpus_donate_spare(sr_corpus* c) {
+  sr_model* m = c->model;
+  if (!m) return;
+  std::unique_ptr<CorpusSpare> sp(new CorpusSpare());
+  swap_spare(c, *sp);
+  std::lock_guard<std::mutex> lk(m->spare_mu);
+  if (!m->spare) m->spare = std::move(sp);  // (else: one spare set is kept, this one is freed on return)
+}
+}  // namespace srhost
+namespace {
 
 int check_model(const sr_model* m) {
   if (!m) return fail(SR_EINVAL, "null model handle");
@@ -698,6 +725,7 @@ int sr_corpus_upload(sr_model* m, const float* feats, const uint64_t* frame_off,
   std::unique_ptr<sr_corpus, int (*)(sr_corpus*)> own(c, sr_corpus_destroy);
   c->model = m; c->n_utts = n_utts; c->n_frames = F;
   c->frame_off.assign(frame_off, frame_off + n_utts + 1);
+  srhost::corpus_adopt_spare(c);
   hipError_t e;
   if ((e = c->feats.ensure((size_t)F * m->dim + 64)) != hipSuccess ||
       (F > 0 && (e = hipMemcpy(c->feats.p, feats, (size_t)F * m->dim * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess) ||
@@ -713,6 +741,7 @@ int sr_corpus_destroy(sr_corpus* c) {
   if (!c) return SR_OK;
   srhost::feeder_join(c);  // an upload still in flight borrows the caller's buffer and writes into c->feats
   if (c->model) { (void)hipSetDevice(c->model->device); (void)hipDeviceSynchronize(); }
+  srhost::corpus_donate_spare(c);  // the search-path buffers stay with the model for its next corpus
   c->feats.release(); c->d_frame_off.release(); c->tb_score.release(); c->tb_word.release(); c->tb_bkp.release();
   c->out_words.release(); c->out_count.release(); c->out_flags.release(); c->automata.release(); c->out_states.release();
   c->aut_off.release(); c->bp_off.release(); c->al_blk_frame0.release(); c->al_list_off.release(); c->al_states.release();
