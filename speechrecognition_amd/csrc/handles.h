@@ -168,6 +168,7 @@ struct sr_bigram {
   float tdp[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   DevBuf<uint32_t> slot_off, slot_mix;
   DevBuf<uint16_t> mixtures;
+  DevBuf<uint32_t> pos_info, pos_slot;
   DevBuf<float> lmT, lm_rowmin, lm_rowmax;
   // workspace
   DevBuf<uint32_t> we_slot, we_bp, out_word, out_time, out_count, out_flags;

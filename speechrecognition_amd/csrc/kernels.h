@@ -183,6 +183,9 @@ struct BigramArgs {
   const uint32_t* slot_off;     // [2W+1] first dense position of every slot
   const uint32_t* slot_mix;     // [2W] offset of the slot's acoustic word in `mixtures`
   const uint16_t* mixtures;     // emission state per lexicon position
+  const uint32_t* pos_info;     // [n_positions] per dense position (slots back to back): emission state | flags << 16
+                                //   flags: 1 = first state of its slot, 2 = second, 4 = last, 8 = silence (copy)
+  const uint32_t* pos_slot;     // [n_positions] its slot
   const float* lmT;             // [W x W] transposed: lmT[h*W + w] = -log p(w | h)
   const float *lm_rowmin, *lm_rowmax;  // [W] min / max over w != silence of lmT[h][w]
   float tdp[2][4];              // [isSilence][loop, forward, skip, exit]

@@ -1057,6 +1057,17 @@ int sr_bigram_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, co
     slot_mix[a] = word_off[aw];
   }
   const uint32_t P2 = slot_off[2 * W];
+  // per dense position: emission state | flags << 16 and the slot (the state update runs one thread per position)
+  std::vector<uint32_t> pos_info(P2);
+  std::vector<uint32_t> pos_slot(P2);
+  for (uint32_t a = 0; a < 2 * W; a++) {
+    const uint32_t n = slot_off[a + 1] - slot_off[a], sil = (a >= W || a == silence_word) ? 8u : 0u;
+    for (uint32_t k = 0; k < n; k++) {
+      const uint32_t flags = (k == 0 ? 1u : 0u) | (k == 1 ? 2u : 0u) | (k == n - 1 ? 4u : 0u) | sil;
+      pos_info[slot_off[a] + k] = (uint32_t)mixtures[slot_mix[a] + k] | (flags << 16);
+      pos_slot[slot_off[a] + k] = a;
+    }
+  }
   if (bigram_lds_bytes(W, P2) > 160 * 1024)
     return fail(SR_ELIMIT, "lexicon too large for the bigram search's LDS image (%zu bytes > 160 KiB)", bigram_lds_bytes(W, P2));
   std::vector<float> lmT((size_t)W * W);
@@ -1079,7 +1090,8 @@ int sr_bigram_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, co
   if ((e = b->slot_off.upload(slot_off.data(), slot_off.size())) != hipSuccess ||
       (e = b->slot_mix.upload(slot_mix.data(), slot_mix.size())) != hipSuccess ||
       (e = b->mixtures.upload(mixtures, word_off[W])) != hipSuccess || (e = b->lmT.upload(lmT.data(), lmT.size())) != hipSuccess ||
-      (e = b->lm_rowmin.upload(rowmin.data(), W)) != hipSuccess || (e = b->lm_rowmax.upload(rowmax.data(), W)) != hipSuccess)
+      (e = b->lm_rowmin.upload(rowmin.data(), W)) != hipSuccess || (e = b->lm_rowmax.upload(rowmax.data(), W)) != hipSuccess ||
+      (e = b->pos_info.upload(pos_info.data(), P2)) != hipSuccess || (e = b->pos_slot.upload(pos_slot.data(), P2)) != hipSuccess)
     return fail(SR_EHIP, "bigram upload: %s", hipGetErrorString(e));
   *out = own.release();
   return SR_OK;
@@ -1090,7 +1102,7 @@ int sr_bigram_destroy(sr_bigram* b) {
   return guarded(__func__, [&]() -> int {
   if (!b) return SR_OK;
   if (b->model) { (void)hipSetDevice(b->model->device); (void)hipDeviceSynchronize(); }
-  b->slot_off.release(); b->slot_mix.release(); b->mixtures.release(); b->lmT.release(); b->lm_rowmin.release(); b->lm_rowmax.release();
+  b->slot_off.release(); b->slot_mix.release(); b->mixtures.release(); b->pos_info.release(); b->pos_slot.release(); b->lmT.release(); b->lm_rowmin.release(); b->lm_rowmax.release();
   b->we_slot.release(); b->we_bp.release(); b->we_score.release(); b->book.release(); b->book_off.release();
   b->out_word.release(); b->out_time.release(); b->out_score.release(); b->out_count.release(); b->out_flags.release();
   delete b;
@@ -1131,7 +1143,7 @@ int sr_recognize_bigram_corpus(sr_model* m, sr_corpus* c, sr_bigram* b, const sr
   if ((rc = ensure_utt_order(m, c, chunks))) return rc;
   ba.ld = m->ld; ba.frame_off = c->d_frame_off.p; ba.utt_order = c->utt_order.p;
   ba.n_words = W; ba.silence = b->silence; ba.n_positions = b->n_positions;
-  ba.slot_off = b->slot_off.p; ba.slot_mix = b->slot_mix.p; ba.mixtures = b->mixtures.p; ba.lmT = b->lmT.p; ba.lm_rowmin = b->lm_rowmin.p; ba.lm_rowmax = b->lm_rowmax.p;
+  ba.slot_off = b->slot_off.p; ba.slot_mix = b->slot_mix.p; ba.mixtures = b->mixtures.p; ba.pos_info = b->pos_info.p; ba.pos_slot = b->pos_slot.p; ba.lmT = b->lmT.p; ba.lm_rowmin = b->lm_rowmin.p; ba.lm_rowmax = b->lm_rowmax.p;
   memcpy(ba.tdp, b->tdp, sizeof(ba.tdp));
   ba.ac_pruning = p->acoustic_pruning; ba.lm_pruning = p->lm_pruning;
   ba.we_slot = b->we_slot.p; ba.we_bp = b->we_bp.p; ba.we_score = b->we_score.p;

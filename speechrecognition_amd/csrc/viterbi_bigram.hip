@@ -38,30 +38,32 @@ static constexpr float kFltMax = 3.402823466e+38f;
 // flags on a word end of the merged list (see step 6): the same word end also sits LATER in the list / sat EARLIER
 static constexpr uint32_t kShadowed = 0x80000000u, kRepeat = 0x40000000u, kSlotMask = 0x3FFFFFFFu;
 
-__device__ inline uint32_t wave_incl_scan(uint32_t v, int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t n = __shfl_up(v, o);
-    if (lane >= o) v += n;
-  }
+// inclusive prefix sum over the wave with DPP row shifts and broadcasts (six vector instructions; __shfl_up is a
+// ds_bpermute round trip per step)
+__device__ inline uint32_t wave_incl_scan(uint32_t v, int /*lane*/) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1, zero fill
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);   // row_shr:2
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);   // row_shr:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);   // row_shr:8
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast15 -> rows 1, 3
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast31 -> rows 2, 3
   return v;
 }
 
 // exclusive prefix of `v` over the workgroup in thread order; total in *total.  `tmp` = kBgWaves + 1 words of LDS.
+// Two barriers: every wave scans the kBgWaves wave totals itself (round 2: a third barrier around a serial loop of thread 0
+// over the 16 totals, ~2 000 cycles, five times a frame).
 __device__ inline uint32_t wg_excl_scan(uint32_t v, uint32_t* tmp, uint32_t* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t inc = wave_incl_scan(v, lane);
   __syncthreads();  // tmp free
   if (lane == 63) tmp[wave] = inc;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = 0;
-    for (int w = 0; w < kBgWaves; w++) { const uint32_t t = tmp[w]; tmp[w] = run; run += t; }
-    tmp[kBgWaves] = run;
-  }
-  __syncthreads();
-  *total = tmp[kBgWaves];
-  return tmp[wave] + inc - v;
+  const uint32_t wt = lane < kBgWaves ? tmp[lane] : 0u;
+  const uint32_t winc = wave_incl_scan(wt, lane);  // lanes 0 .. kBgWaves-1: inclusive prefix of the wave totals
+  *total = (uint32_t)__builtin_amdgcn_readlane((int)winc, kBgWaves - 1);
+  const uint32_t before = (uint32_t)__shfl((int)(winc - wt), wave);  // exclusive prefix of this wave (wave-uniform index)
+  return before + inc - v;
 }
 
 __device__ inline float wg_min(float v, float* tmp) {
@@ -70,12 +72,13 @@ __device__ inline float wg_min(float v, float* tmp) {
   __syncthreads();
   if ((threadIdx.x & 63) == 0) tmp[threadIdx.x >> 6] = v;
   __syncthreads();
-  float r = tmp[0];
-  for (int w = 1; w < kBgWaves; w++) r = fminf(r, tmp[w]);
+  float r = tmp[threadIdx.x & (kBgWaves - 1)];  // one read; the 16 partials sit in every row of 16 lanes
+#pragma unroll
+  for (int o = kBgWaves / 2; o > 0; o >>= 1) r = fminf(r, __shfl_xor(r, o));
   return r;
 }
 
-template <int KW>  // words per thread in the recombination: W <= KW * kBgThreads
+template <int KW, int KP>  // words per thread in the recombination: W <= KW * kBgThreads; positions per thread in the state update
 __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t W = a.n_words, W2 = 2 * a.n_words, P2 = a.n_positions, sil = a.silence;
@@ -121,7 +124,8 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
   }
   __syncthreads();
   bool overflow = false;
-
+  const __amdgpu_buffer_rsrc_t info_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.pos_info), 0, (int)(P2 * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t slot_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.pos_slot), 0, (int)(P2 * 4u), 0x00020000);
   for (uint64_t t = 1; t <= T; t++) {
     // ---- 1 bigramRecombination + LM beam ------------------------------------------------------------------------
     for (uint32_t i = W + tid; i < W2; i += kBgThreads) en_score[i] = __builtin_inff();
@@ -275,66 +279,126 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
       __syncthreads();
     }
 
-    // ---- 3 expandHypotheses + addAcousticScores; thread k owns the contiguous list entries [k*cl, (k+1)*cl) ---------
-    const uint32_t cl = (n_L + kBgThreads - 1) / kBgThreads;
-    const uint32_t i_lo = tid * cl, i_hi = (i_lo + cl < n_L) ? i_lo + cl : n_L;
+    // ---- 3 expandHypotheses + addAcousticScores, one thread per POSITION (round 3) --------------------------------------
+    // Position j = tid + k * 1024: consecutive lanes hold consecutive positions, i.e. consecutive states of a word -- the LDS
+    // accesses are conflict-free and the emission gather of a wave is a few contiguous cache lines.  (Rounds 1-2 walked the
+    // active list, one thread per slot: neighbouring threads were 15-16 positions apart = a 16-way bank conflict on every
+    // state access, and every emission gather touched 64 cache lines; the step took 34 000 of a frame's 104 000 cycles.)
+    // A slot that is not active holds +inf everywhere and has no entry hypothesis, so updating it is a no-op; the new state s
+    // needs the OLD states s-2, s-1, s: all reads, a barrier, then the writes.  Candidates in the order the reference creates
+    // them (ascending predecessor state, entry first); >= lets the later one win.
     const double* row = dense + (t - 1) * a.ld;
+    // kCh positions at a time: emission state | flags, slot (frame-invariant, but held in registers across the frame loop they
+    // spill: coalesced reloads are cheaper) and emission cost, loads in flight together, then the four updates.
+    constexpr int kCh = 4;
+    static_assert(KP % kCh == 0, "positions per thread come in chunks of four");
+    float nsc[KP];
+    uint32_t nbp[KP];
     float lbest = kFltMax;
-    for (uint32_t i = i_lo; i < i_hi; i++) {
-      const uint32_t sl = L[lcur][i];
-      const uint32_t base = a.slot_off[sl], n = a.slot_off[sl + 1] - base, mixbase = a.slot_mix[sl];
-      const int s_ = is_sil(sl);
-      const float t0 = a.tdp[s_][0], t1 = a.tdp[s_][1], t2 = a.tdp[s_][2];
-      const float ent = en_score[sl];
-      const uint32_t ent_bp = en_bp[sl];
-      for (uint32_t s = n; s >= 1; s--) {  // in place: the new state s needs the old states s-2, s-1, s only
-        float best = __builtin_inff();
-        uint32_t bbp = 0;
-        // candidates in the order the reference creates them: ascending predecessor state; >= lets the later one win
-        if (s <= 2 && ent < __builtin_inff()) {  // from the virtual entry state 0: free to state 1, skip penalty to state 2
-          const float c = (s == 1) ? ent : ent + t2;
-          best = c; bbp = ent_bp;
-        }
-        if (s >= 3) {
-          const float o = st_score[base + s - 3];
-          if (o < __builtin_inff()) { const float c = o + t2; if (!(best < c)) { best = c; bbp = st_bp[base + s - 3]; } }
-        }
-        if (s >= 2) {
-          const float o = st_score[base + s - 2];
-          if (o < __builtin_inff()) { const float c = o + t1; if (!(best < c)) { best = c; bbp = st_bp[base + s - 2]; } }
-        }
-        {
-          const float o = st_score[base + s - 1];
-          if (o < __builtin_inff()) { const float c = o + t0; if (!(best < c)) { best = c; bbp = st_bp[base + s - 1]; } }
-        }
-        if (best < __builtin_inff()) {
-          best += (float)row[a.mixtures[mixbase + s - 1]];
+#pragma unroll
+    for (int k0 = 0; k0 < KP; k0 += kCh) {
+    __builtin_amdgcn_sched_barrier(0);  // (chunks interleaved by the scheduler need more registers than there are)
+    uint32_t pinfo[kCh], pslot[kCh];
+    float pem[kCh];
+#pragma unroll
+    for (int q = 0; q < kCh; q++) {
+      const uint32_t j = tid + (uint32_t)(k0 + q) * kBgThreads;
+      // (buffer loads: one VGPR offset for all positions, the k * 4096 bytes as a scalar offset -- as plain pointers the compiler
+      // hoists KP 64-bit addresses per table out of the frame loop and spills them; out of range reads return 0)
+      pinfo[q] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(info_rsrc, tid * 4u, (uint32_t)(k0 + q) * (kBgThreads * 4u), 0);
+      pslot[q] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(slot_rsrc, tid * 4u, (uint32_t)(k0 + q) * (kBgThreads * 4u), 0);
+      (void)j;
+    }
+#pragma unroll
+    for (int q = 0; q < kCh; q++) pem[q] = (float)row[pinfo[q] & 0xFFFFu];
+    // Four positions at a time, branch-free: (a) every candidate's old score is read unconditionally (an address that does not
+    // apply is clamped to the position itself, its value replaced by +inf), (b) the decisions, pure arithmetic, (c) the winners'
+    // back pointers -- two LDS round trips per four positions instead of five per position behind divergent branches.
+    constexpr int kL = 4;
+    static_assert(kCh % kL == 0, "");
+#pragma unroll
+    for (int q0 = 0; q0 < kCh; q0 += kL) {
+      float c_ent[kL], c_o3[kL], c_o2[kL], c_o1[kL];
+#pragma unroll
+      for (int r = 0; r < kL; r++) {
+        const uint32_t j = tid + (uint32_t)(k0 + q0 + r) * kBgThreads, jj = j < P2 ? j : 0u;
+        const uint32_t fl = pinfo[q0 + r] >> 16;
+        c_ent[r] = en_score[pslot[q0 + r]];
+        c_o3[r] = st_score[(fl & 3u) ? jj : jj - 2];
+        c_o2[r] = st_score[(fl & 1u) ? jj : jj - 1];
+        c_o1[r] = st_score[jj];
+      }
+      uint32_t srcs[kL];  // where the winner's back pointer lives: 0xFFFFFFFF none, 0x80000000 | slot = entry, else position
+#pragma unroll
+      for (int r = 0; r < kL; r++) {
+        const int q = q0 + r, k = k0 + q;
+        const uint32_t j = tid + (uint32_t)k * kBgThreads;
+        const uint32_t fl = pinfo[q] >> 16, sl = pslot[q];
+        const bool sil_ = (fl >> 3) & 1u, in = j < P2;
+        const float t0 = sil_ ? a.tdp[1][0] : a.tdp[0][0], t1 = sil_ ? a.tdp[1][1] : a.tdp[0][1], t2 = sil_ ? a.tdp[1][2] : a.tdp[0][2];
+        const float inf = __builtin_inff();
+        // states 1 and 2 are reachable from the virtual entry state 0: free to state 1, skip penalty to state 2
+        const float ent = (in && (fl & 3u)) ? c_ent[r] : inf;
+        const float o3 = (in && !(fl & 3u)) ? c_o3[r] : inf;  // s >= 3: skip from s - 2
+        const float o2 = (in && !(fl & 1u)) ? c_o2[r] : inf;  // s >= 2: forward from s - 1
+        const float o1 = in ? c_o1[r] : inf;                  // loop
+        float best = inf;
+        uint32_t src = 0xFFFFFFFFu;
+        if (ent < inf) { best = (fl & 1u) ? ent : ent + t2; src = 0x80000000u | sl; }
+        { const float c = o3 + t2; if (o3 < inf && !(best < c)) { best = c; src = j - 2; } }
+        { const float c = o2 + t1; if (o2 < inf && !(best < c)) { best = c; src = j - 1; } }
+        { const float c = o1 + t0; if (o1 < inf && !(best < c)) { best = c; src = j; } }
+        if (best < inf) {
+          best += pem[q];
           lbest = fminf(lbest, best);
         }
-        st_score[base + s - 1] = best;
-        st_bp[base + s - 1] = bbp;
+        nsc[k] = best;
+        srcs[r] = src;
+      }
+#pragma unroll
+      for (int r = 0; r < kL; r++) {
+        const uint32_t src = srcs[r];
+        // en_bp follows st_bp's neighbour arrays in LDS: one read through a common base (st_bp) with a signed word offset
+        const uint32_t idx = src == 0xFFFFFFFFu ? 0u : (src & 0x80000000u) ? (uint32_t)(en_bp - st_bp) + (src & 0x7FFFFFFFu) : src;
+        const uint32_t v = st_bp[idx];
+        nbp[k0 + q0 + r] = src == 0xFFFFFFFFu ? 0u : v;
       }
     }
+    }
+    __syncthreads();  // every old state has been read
+#pragma unroll
+    for (int k = 0; k < KP; k++) {
+      const uint32_t j = tid + (uint32_t)k * kBgThreads;
+      if (j < P2) { st_score[j] = nsc[k]; st_bp[j] = nbp[k]; }
+    }
+    for (uint32_t i = tid; i < W2; i += kBgThreads) active[i] &= 1u;  // bit 0 = on the active list; bits 1, 2 = this frame's survivors
     const float best_score = wg_min(lbest, red_tmp);
     float ac_thr = a.ac_pruning;
     if (ac_thr < kFltMax) ac_thr += best_score;
 
-    // ---- 4 pruneStatesAndFindWordEnds: ordered compaction of the active list and of the word ends ------------------
-    uint32_t n_alive = 0, n_ends = 0;
-    for (uint32_t i = i_lo; i < i_hi; i++) {
-      const uint32_t sl = L[lcur][i];
-      const uint32_t base = a.slot_off[sl], n = a.slot_off[sl + 1] - base;
-      const float xp = exit_pen[is_sil(sl)];
-      bool alive = false;
-      for (uint32_t s = 1; s <= n; s++) {
-        const float sc = st_score[base + s - 1];
-        if (sc < __builtin_inff()) {
-          const float tv = sc + xp;
-          if (tv < ac_thr) { alive = true; if (s == n) n_ends++; }
-          else st_score[base + s - 1] = __builtin_inff();
+    // ---- 4 pruneStatesAndFindWordEnds: the acoustic beam per position, then the ordered compaction of the active list ---
+    {
+      uint32_t* active_w = reinterpret_cast<uint32_t*>(active);  // (byte flags, OR-ed through their 32-bit word)
+#pragma unroll
+      for (int k = 0; k < KP; k++) {
+        const uint32_t j = tid + (uint32_t)k * kBgThreads;
+        if (j < P2 && nsc[k] < __builtin_inff()) {
+          const uint32_t fl = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(info_rsrc, tid * 4u, (uint32_t)k * (kBgThreads * 4u), 0) >> 16;
+          const uint32_t sl = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(slot_rsrc, tid * 4u, (uint32_t)k * (kBgThreads * 4u), 0);
+          const float tv = nsc[k] + exit_pen[(fl >> 3) & 1];  // (nsc: what this thread stored at st_score[j] above)
+          if (tv < ac_thr) atomicOr(&active_w[sl >> 2], ((fl & 4u) ? 6u : 2u) << (8u * (sl & 3u)));  // alive; its final state too
+          else st_score[j] = __builtin_inff();
         }
       }
-      if (alive) n_alive++; else active[sl] = 0;
+    }
+    __syncthreads();
+    const uint32_t cl = (n_L + kBgThreads - 1) / kBgThreads;
+    const uint32_t i_lo = tid * cl, i_hi = (i_lo + cl < n_L) ? i_lo + cl : n_L;
+    uint32_t n_alive = 0, n_ends = 0;
+    for (uint32_t i = i_lo; i < i_hi; i++) {
+      const uint32_t fa = active[L[lcur][i]];
+      n_alive += (fa >> 1) & 1u;
+      n_ends += (fa >> 2) & 1u;
     }
     uint32_t tot_alive, tot_ends;
     uint32_t pa = wg_excl_scan(n_alive, scan_tmp, &tot_alive);
@@ -342,14 +406,15 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
     const int nxt = cur ^ 1;
     for (uint32_t i = i_lo; i < i_hi; i++) {
       const uint32_t sl = L[lcur][i];
-      if (!active[sl]) continue;
+      const uint32_t fa = active[sl];
+      if (!(fa & 2u)) { active[sl] = 0; continue; }
+      active[sl] = 1;
       L[lcur ^ 1][pa++] = (uint16_t)sl;
-      const uint32_t base = a.slot_off[sl], n = a.slot_off[sl + 1] - base;
-      const float sc = st_score[base + n - 1];
-      if (sc < __builtin_inff()) {  // the final state survived: a word end, carrying the exit-penalised score
+      if (fa & 4u) {  // the final state survived: a word end, carrying the exit-penalised score
+        const uint32_t last = a.slot_off[sl + 1] - 1;
         we_slot[nxt][pe] = sl;
-        we_score[nxt][pe] = sc + exit_pen[is_sil(sl)];
-        we_bp[nxt][pe] = st_bp[base + n - 1];
+        we_score[nxt][pe] = st_score[last] + exit_pen[is_sil(sl)];
+        we_bp[nxt][pe] = st_bp[last];
         pe++;
       }
     }
@@ -449,11 +514,15 @@ hipError_t launch_bigram(const BigramArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(kernel, dim3(a.n_utts), dim3(kBgThreads), smem, stream, a);
     return hipGetLastError();
   };
-  const uint32_t kw = (a.n_words + kBgThreads - 1) / kBgThreads;
-  if (kw <= 1) return go(bigram_kernel<1>);
-  if (kw <= 2) return go(bigram_kernel<2>);
-  if (kw <= 4) return go(bigram_kernel<4>);
-  return go(bigram_kernel<8>);
+  const uint32_t kw = (a.n_words + kBgThreads - 1) / kBgThreads, kp = (a.n_positions + kBgThreads - 1) / kBgThreads;
+#define SR_BG(KWv, KPv) return go(bigram_kernel<KWv, KPv>)
+#define SR_BG_KP(KWv) do { if (kp <= 4) SR_BG(KWv, 4); if (kp <= 12) SR_BG(KWv, 12); if (kp <= 20) SR_BG(KWv, 20); return hipErrorInvalidValue; } while (0)
+  if (kw <= 1) SR_BG_KP(1);
+  if (kw <= 2) SR_BG_KP(2);
+  if (kw <= 4) SR_BG_KP(4);
+  SR_BG_KP(8);
+#undef SR_BG_KP
+#undef SR_BG
 }
 
 }  // namespace srgpu

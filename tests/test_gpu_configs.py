@@ -129,6 +129,41 @@ def test_cfg5_bigram_at_size_vs_restatement(tmp_path, oracle_lib):
         assert np.array_equal(s1[a:b].view(np.uint32), s2[a2:b2].view(np.uint32)), u
 
 
+def test_cfg5_bigram_lm_beam_on_at_size(tmp_path, oracle_lib):
+    """configs[4] with the LM beam ON (LinearSearch.cc:499-503: start hypotheses beyond best_start + lm-pruning are dropped;
+    rounds 1-2 only ran it up to 2200 words): 8000 states x 64, 2667 words, acoustic beam 200, lm-pruning 4 and 9 -- against
+    orc_bigram_decode on three utterances each (words, times, scores bit for bit).  PARITY UNPINNED: the restatement of
+    Teaching::LinearSearch is the specification (rwth-asr cannot be built here); the test also checks that the beam bites,
+    i.e. that the tight beam activates fewer start hypotheses than no beam."""
+    lex, spec, mp, word_off, mixtures, lm, tdp = _cfg5_setup(tmp_path)
+    rng = np.random.default_rng(52)
+    utts = [synth.make_features(int(n), 39, seed=60 + i) for i, n in enumerate((28, 41, 55))]
+    utts[2] = synth.sample_utterance(spec, lex, rng.integers(1, lex.n_words, size=5), seed=53, frames_per_state=(2, 4))[:55]
+    off = np.concatenate([[0], np.cumsum([len(x) for x in utts])]).astype(np.uint64)
+    o = oracle_lib.Oracle(mp, 39, lex)
+    dense = [o.score_matrix(x, n_threads=16) for x in utts]
+    o.close()
+    starts = {}
+    with capi.Model.from_mixset(mp, 39) as m:
+        bg = m.bigram(word_off, mixtures, lex.silence_idx, lm, tdp)
+        corpus = m.upload(np.concatenate(utts), off)
+        for lm_beam in (4.0, 9.0, capi.FLT_MAX):
+            gw, gs, gt, goff = corpus.recognize_bigram(bg, 200.0, lm_beam)
+            n_started = 0
+            for u, d in enumerate(dense):
+                w, sc, t, st = oracle_lib.bigram_decode(d, word_off, mixtures, lex.silence_idx, lm, tdp, 200.0, lm_beam, stats=True)
+                n_started += int(st[1])
+                a, b = int(goff[u]), int(goff[u + 1])
+                assert len(w) > 0
+                assert np.array_equal(gw[a:b], w), (lm_beam, u)
+                assert np.array_equal(gt[a:b], t), (lm_beam, u)
+                assert np.array_equal(gs[a:b].view(np.uint32), sc.view(np.uint32)), (lm_beam, u)
+            starts[lm_beam] = n_started
+        corpus.close()
+        bg.close()
+    assert starts[4.0] < starts[9.0] < starts[capi.FLT_MAX], starts   # the LM beam prunes start hypotheses
+
+
 def test_global_pooling_em_iteration_on_device(tmp_path):
     """pooling = 0 (MixtureModel::GLOBAL_POOLING, Mixtures.cpp:431-450) on the EM side, against what the REFERENCE wrote
     (tests/golden/global_pooling.npz): accumulators bit for bit, the MIXSET file byte for byte (sha256 of the reference's
