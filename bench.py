@@ -323,18 +323,18 @@ def decode_geometry(P, n_utts):
 
 
 def search_report(args, prof, S, P, P_padded, n_frames, n_utts):
-    """The Viterbi step against SURVEY 8(d)'s HBM model (8*S + 4*P bytes per frame), next to what the counters say bounds
-    it: the frame-sequential recursion issues ~100 vector + ~40 scalar instructions per slot and frame and keeps the SIMDs
-    issuing in 98 % of the cycles (profiles/r2_decoder_one_barrier_experiment.txt) -- HBM is at a fifth of its peak."""
+    """The Viterbi step against SURVEY 8(d)'s HBM model (8*S + 4*P bytes per frame), next to what bounds it: the
+    frame-sequential recursion is a chain of ~380 instructions per wave and frame between two workgroup barriers, one
+    workgroup per CU (profiles/r3_decoder_diet.txt) -- HBM, which only delivers the score rows, is at a quarter of its peak."""
     ms = prof["search_ms"] / max(1, args.steps)
     algorithmic = prof["search_bytes"] / (prof["search_ms"] * 1e-3) / 1e9 if prof["search_ms"] > 0 else 0.0
     traffic = pmc_traffic(args, n_frames, "decode_fast_kernel")
     geom = decode_geometry(P_padded, n_utts)
     return {
-        "kernel": (f"decode_fast_kernel<{geom}> (+ decode_kernel replay of flagged utterances)" if geom else
+        "kernel": (f"decode_fast_kernel<{geom}> (score rows staged in LDS by LDS-DMA when they fit; + decode_kernel replay of flagged utterances)" if geom else
                    "decode_big_kernel<1024> (hypotheses in device memory: more than 8192 type-padded slots)"),
         "ms_per_step": ms,
-        "bound": "instruction issue (VALU+SALU active in ~98 % of the SIMD cycles); not HBM",
+        "bound": "latency of the per-frame dependency chain (two barriers per frame, one workgroup of 16 waves per CU); not HBM",
         "hbm_model": {"bytes_per_frame": 8.0 * S + 4.0 * P, "achieved_GBps": algorithmic, "peak_GBps": 8000.0, "frac": algorithmic / 8000.0},
         "hbm_measured_bytes_per_launch": traffic,
         "hbm_measured_GBps": traffic / (ms * 1e-3) / 1e9 if traffic and ms > 0 else None,
