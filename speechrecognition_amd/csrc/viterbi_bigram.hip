@@ -51,12 +51,13 @@ __device__ inline uint32_t wave_incl_scan(uint32_t v, int /*lane*/) {
 }
 
 // exclusive prefix of `v` over the workgroup in thread order; total in *total.  `tmp` = kBgWaves + 1 words of LDS.
-// Two barriers: every wave scans the kBgWaves wave totals itself (round 2: a third barrier around a serial loop of thread 0
+// ONE barrier: every wave scans the kBgWaves wave totals itself (round 2: a third barrier around a serial loop of thread 0
 // over the 16 totals, ~2 000 cycles, five times a frame).
 __device__ inline uint32_t wg_excl_scan(uint32_t v, uint32_t* tmp, uint32_t* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const uint32_t inc = wave_incl_scan(v, lane);
-  __syncthreads();  // tmp free
+  // (no barrier before the write: every call site has a workgroup barrier between the previous scan's reads of `tmp` -- they
+  // follow its barrier at once -- and this one)
   if (lane == 63) tmp[wave] = inc;
   __syncthreads();
   const uint32_t wt = lane < kBgWaves ? tmp[lane] : 0u;
@@ -69,8 +70,7 @@ __device__ inline uint32_t wg_excl_scan(uint32_t v, uint32_t* tmp, uint32_t* tot
 __device__ inline float wg_min(float v, float* tmp) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) tmp[threadIdx.x >> 6] = v;
+  if ((threadIdx.x & 63) == 0) tmp[threadIdx.x >> 6] = v;  // (as in wg_excl_scan: a barrier lies between two uses of `tmp`)
   __syncthreads();
   float r = tmp[threadIdx.x & (kBgWaves - 1)];  // one read; the 16 partials sit in every row of 16 lanes
 #pragma unroll
@@ -150,47 +150,43 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
       stg = reinterpret_cast<uint32_t*>(L[lcur ^ 1]);
       stg_cap = (W2 * 2u) / 12u < (uint32_t)kBgThreads ? (W2 * 2u) / 12u : (uint32_t)kBgThreads;
     }
-    for (uint32_t e0 = 0; e0 < n_we; e0 += stg_cap) {
-      const uint32_t ne_in = (n_we - e0 < stg_cap) ? n_we - e0 : stg_cap;
-      __syncthreads();
-      // stage the surviving word ends of this chunk, in list order (ballot prefix within the chunk's four waves)
-      bool keep = false;
-      uint32_t h = 0;
-      float sc_e = 0.0f;
-      uint32_t bp_e = 0;
-      if (tid < ne_in) {
-        const uint32_t raw = we_slot[cur][e0 + tid], sl = raw & kSlotMask;
-        h = map_copy(sl);
-        sc_e = we_score[cur][e0 + tid];
-        bp_e = we_bp[cur][e0 + tid];
-        keep = !(sc_e + a.lm_rowmin[h] > U);
-        // transition into the silence copy of the word that ended (no LM cost); where the merge left the same word end
-        // twice in the list, addEntryStateHypothesis (:257-268) keeps the LATER start hypothesis
-        if (sl < W && !(raw & kShadowed)) {
-          const uint32_t c = sil_copy(sl);
-          en_score[c] = sc_e;
-          en_bp[c] = bp_e;
-        }
+    // One pass over the word ends, thread k owning the contiguous entries [k * ce, (k + 1) * ce): the silence-copy transitions, the
+    // skip test, and an ordered scan that gives every survivor its place in the staging buffer (round 2 staged chunk after chunk
+    // of the list, three barriers per chunk, although on most frames one or two word ends survive the skip test at all).
+    const uint32_t ce1 = (n_we + kBgThreads - 1) / kBgThreads;
+    const uint32_t e1_lo = tid * ce1 < n_we ? tid * ce1 : n_we, e1_hi = (e1_lo + ce1 < n_we) ? e1_lo + ce1 : n_we;
+    uint32_t n_keep = 0;
+    for (uint32_t e = e1_lo; e < e1_hi; e++) {
+      const uint32_t raw = we_slot[cur][e], sl = raw & kSlotMask;
+      const float sc_e = we_score[cur][e];
+      // transition into the silence copy of the word that ended (no LM cost); where the merge left the same word end
+      // twice in the list, addEntryStateHypothesis (:257-268) keeps the LATER start hypothesis
+      if (sl < W && !(raw & kShadowed)) {
+        const uint32_t c = sil_copy(sl);
+        en_score[c] = sc_e;
+        en_bp[c] = we_bp[cur][e];
       }
-      const uint64_t bal = __ballot(keep);
-      if ((tid & 63) == 0) scan_tmp[tid >> 6] = (uint32_t)__popcll(bal);
-      __syncthreads();
-      uint32_t ne = 0;
-      {
-        uint32_t before = 0;
-        for (int wv = 0; wv < kBgWaves; wv++) {
-          const uint32_t c = scan_tmp[wv];
-          if (wv < (int)(tid >> 6)) before += c;
-          ne += c;
-        }
-        if (keep) {
-          const uint32_t pos = before + (uint32_t)__popcll(bal & ((1ull << (tid & 63)) - 1ull));
-          stg[3 * pos] = h;
-          stg[3 * pos + 1] = __float_as_uint(sc_e);
-          stg[3 * pos + 2] = bp_e;
+      n_keep += !(sc_e + a.lm_rowmin[map_copy(sl)] > U) ? 1u : 0u;
+    }
+    uint32_t ne_all;
+    const uint32_t keep_pos = wg_excl_scan(n_keep, scan_tmp, &ne_all);
+    for (uint32_t r0 = 0; r0 < ne_all; r0 += stg_cap) {  // (one round unless more word ends survive than the staging buffer holds)
+      if (r0) __syncthreads();  // the previous round's rows have been read
+      uint32_t pos = keep_pos;
+      for (uint32_t e = e1_lo; e < e1_hi; e++) {
+        const uint32_t sl = we_slot[cur][e] & kSlotMask, h = map_copy(sl);
+        const float sc_e = we_score[cur][e];
+        if (!(sc_e + a.lm_rowmin[h] > U)) {
+          if (pos >= r0 && pos - r0 < stg_cap) {
+            stg[3 * (pos - r0)] = h;
+            stg[3 * (pos - r0) + 1] = __float_as_uint(sc_e);
+            stg[3 * (pos - r0) + 2] = we_bp[cur][e];
+          }
+          pos++;
         }
       }
       __syncthreads();
+      const uint32_t ne = (ne_all - r0 < stg_cap) ? ne_all - r0 : stg_cap;
       // eight word ends at a time: their LM rows are loaded first (independent loads in flight together), then
       // compared in list order
       for (uint32_t e = 0; e < ne; e += 8) {
@@ -249,25 +245,27 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
         if (!ins) en_score[w] = __builtin_inff();
         else if (!active[w]) cnt++;
       }
-      uint32_t total;
-      uint32_t pos = n_L + wg_excl_scan(cnt, scan_tmp, &total);
-      for (uint32_t w = w_lo; w < w_hi; w++)
-        if (w != sil && en_score[w] < __builtin_inff() && !active[w]) { L[lcur][pos++] = (uint16_t)w; active[w] = 1; }
-      n_L += total;
-      // (b) silence copies, in the order of the word ends that start them
+      // (b) silence copies, in the order of the word ends that start them.  (a) and (b) touch disjoint slots -- words other than
+      // silence there, silence and the copies here -- so both are counted first and ONE scan (16 bits each) places both
       const uint32_t ce = (n_we + kBgThreads - 1) / kBgThreads;
-      const uint32_t e_lo = tid * ce, e_hi = (e_lo + ce < n_we) ? e_lo + ce : n_we;
-      cnt = 0;
+      const uint32_t e_lo = tid * ce < n_we ? tid * ce : n_we, e_hi = (e_lo + ce < n_we) ? e_lo + ce : n_we;
+      uint32_t cnt_b = 0;
       for (uint32_t e = e_lo; e < e_hi; e++) {
         const uint32_t raw = we_slot[cur][e], sl = raw & kSlotMask;
         if (sl < W && !(raw & kRepeat)) {  // (a repeated word end activates nothing new: its first occurrence did)
           const uint32_t c = sil_copy(sl);
           const bool ins = en_score[c] < lm_thr;
           if (!ins) en_score[c] = __builtin_inff();
-          else if (!active[c]) cnt++;
+          else if (!active[c]) cnt_b++;
         }
       }
-      pos = n_L + wg_excl_scan(cnt, scan_tmp, &total);
+      uint32_t total;
+      const uint32_t ex = wg_excl_scan(cnt | (cnt_b << 16), scan_tmp, &total);
+      uint32_t pos = n_L + (ex & 0xFFFFu);
+      for (uint32_t w = w_lo; w < w_hi; w++)
+        if (w != sil && en_score[w] < __builtin_inff() && !active[w]) { L[lcur][pos++] = (uint16_t)w; active[w] = 1; }
+      n_L += total & 0xFFFFu;
+      pos = n_L + (ex >> 16);
       for (uint32_t e = e_lo; e < e_hi; e++) {
         const uint32_t raw = we_slot[cur][e], sl = raw & kSlotMask;
         if (sl < W && !(raw & kRepeat)) {
@@ -275,7 +273,7 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
           if (en_score[c] < __builtin_inff() && !active[c]) { L[lcur][pos++] = (uint16_t)c; active[c] = 1; }
         }
       }
-      n_L += total;
+      n_L += total >> 16;
       __syncthreads();
     }
 
@@ -400,9 +398,11 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
       n_alive += (fa >> 1) & 1u;
       n_ends += (fa >> 2) & 1u;
     }
-    uint32_t tot_alive, tot_ends;
-    uint32_t pa = wg_excl_scan(n_alive, scan_tmp, &tot_alive);
-    uint32_t pe = wg_excl_scan(n_ends, scan_tmp, &tot_ends);
+    // one scan for both counts (16 bits each: at most 2W = 16 384 slots)
+    uint32_t tot_both;
+    const uint32_t p_both = wg_excl_scan(n_alive | (n_ends << 16), scan_tmp, &tot_both);
+    const uint32_t tot_alive = tot_both & 0xFFFFu, tot_ends = tot_both >> 16;
+    uint32_t pa = p_both & 0xFFFFu, pe = p_both >> 16;
     const int nxt = cur ^ 1;
     for (uint32_t i = i_lo; i < i_hi; i++) {
       const uint32_t sl = L[lcur][i];
