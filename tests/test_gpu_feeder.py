@@ -118,3 +118,33 @@ def test_multi_device_driver_equals_single_handle(tmp_path, n_replicas):
             l.close()
         for m in models:
             m.close()
+
+
+def test_corpus_buffers_recycled_across_calls(tmp_path):
+    """A model keeps the device buffers of its last destroyed corpus for the next one (round 3: the nine allocations per
+    sr_recognize_batch call were a millisecond of the boundary step).  Batches of different sizes through ONE model, blocking and
+    asynchronous uploads interleaved, a second corpus alive at the same time: every result equals a fresh model's."""
+    lex, spec, mp = _setup(tmp_path, W=40, M=3)
+    word_off, automaton, sil = lex.flatten()
+    batches = [synth.make_batch(n, 20, 90, 39, seed=20 + i) for i, n in enumerate((120, 7, 300, 1, 64))]
+    want = []
+    for feats, off in batches:
+        with capi.Model.from_mixset(mp, 39) as m:
+            lexh = m.lexicon(word_off, automaton, lex.silence_idx, TDP, sil)
+            want.append(m.recognize_batch(lexh, feats, off, 150.0, 10.0))
+            lexh.close()
+    with capi.Model.from_mixset(mp, 39) as m:
+        lexh = m.lexicon(word_off, automaton, lex.silence_idx, TDP, sil)
+        for rnd in range(2):
+            for i, (feats, off) in enumerate(batches):
+                if (i + rnd) % 2:
+                    w, o = m.recognize_batch(lexh, feats, off, 150.0, 10.0)          # asynchronous feeder, corpus created + destroyed
+                else:
+                    c = m.upload(feats, off)                                           # blocking upload
+                    keep = m.upload(batches[1][0], batches[1][1], asynchronous=True)   # a second corpus at the same time
+                    w, o = c.recognize(lexh, 150.0, 10.0)
+                    w2, o2 = keep.recognize(lexh, 150.0, 10.0)
+                    assert np.array_equal(w2, want[1][0]) and np.array_equal(o2, want[1][1])
+                    c.close(); keep.close()
+                assert np.array_equal(w, want[i][0]) and np.array_equal(o, want[i][1]), (rnd, i)
+        lexh.close()
