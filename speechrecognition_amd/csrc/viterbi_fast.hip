@@ -8,10 +8,10 @@
 //     the general kernel becomes a wave-uniform branch, a slot evaluates only the candidates its type has, and
 //     penalties are scalars.  Predecessors are explicit slot ids (the sort breaks p-1 / p-2 adjacency).
 //   * it assumes every emission cost of the frame is >= 0, which makes the reference's pre-AM early-out
-//     (Recognizer.cpp:143,173) inert so a slot is the first minimum over its candidates in source order; the
-//     first negative cost raises out_flags bit 1 and the workgroup stops: decode_kernel<.., REPLAY=true>
-//     then redoes that utterance exactly.
-//   * wave reductions use DPP row operations instead of LDS permutes.
+//     (Recognizer.cpp:143,173) inert so a slot is the first minimum over its candidates in source order; an
+//     utterance in which any emission cost was negative (or not a number) is flagged after its last frame
+//     (out_flags kFlagReplay, no words reported) and decode_kernel<.., REPLAY=true> redoes it exactly.
+//   * reductions use DPP row operations and LDS ds_min_f64 cells; the frame's score row is staged in LDS by LDS-DMA.
 //
 // Ties are broken by ORIGINAL slot index (the reference's visiting order), which every slot carries along.
 #include <hip/hip_runtime.h>
@@ -111,13 +111,14 @@ struct Cell { double score; uint32_t bkp; };
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // Round 3 ("instruction diet"): the frame loop was 260 vector instructions per wave and frame for 4 slots per
-// lane; this version issues ~90.  What went:
-//   * the emission cost of a slot stays in a register from its (one frame ahead) gather; position-1 slots gather position
-//     0's cost themselves (the boundary quirk, Recognizer.cpp:148-151) instead of reading it from an LDS copy every slot wrote;
+// lane; this version issues 174 (profiles/r3_decoder_diet.txt).  What went:
+//   * no LDS copy of the frame's emission costs that every slot wrote and position-1 slots read (the boundary quirk,
+//     Recognizer.cpp:148-151: they are scored with position 0's emission): a slot reads its cost -- and position 0's -- where the
+//     row is (ROWS, below) or keeps its own one-frame-ahead gathers in registers;
 //   * candidates merge as v_min_f64 + one compare + one select of the back pointer (first-wins ties = strict '<' on the later
-//     candidate), not compare + three selects; the word-boundary candidate is one add per slot -- (m_we + wp) + tdp is computed
-//     once per wave and frame -- and is skipped altogether while no word end is alive; its tie order against the in-word
-//     candidates (first word-end index per class vs. the slot's own word) is only looked at when a tie is there;
+//     candidate), not compare + three selects; the word-boundary candidate is one add per slot -- (m_we + wp) + tdp is the same
+//     in every lane (+inf while no word end is alive) -- and its tie order against the in-word candidates (first word-end
+//     index per class vs. the slot's own word) is patched in after the block, only when a wave sees a tie;
 //   * "emission cost < 0 or NaN" (the fast path's premise, see the file header) is one compare per slot into a scalar mask
 //     that is looked at once, after the last frame, instead of an LDS flag and a workgroup-uniform branch per frame;
 //   * the block minimum and the word-end minimum are LDS ds_min_f64 cells (by frame parity) fed by four lanes per wave after a
