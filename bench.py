@@ -348,13 +348,24 @@ def prefilter_report(args, prof, n_frames, D, S):
     p_flops = 2.0 * k * (32 * 4 * ((S + 3) // 4)) * n_frames  # executed: one fp16 product, K and states padded
     p_useful = 2.0 * (2 * D + 3) * S * args.mix * n_frames     # useful: K = 2 D + 3 per real density
     dense = 4.0 * D * S * args.mix * n_frames
+    # matrix-pipe busy share from the committed counters (same workload, same kernel sources): SQ_VALU_MFMA_BUSY_CYCLES over
+    # 128 pipe-cycles per GRBM_GUI_ACTIVE cycle (4 SIMDs x 256 CUs / 8 XCDs: the counter sums the XCDs)
+    busy = None
+    z = pmc_summary(args, n_frames)
+    if z is not None:
+        for name, k in z.get("kernels", {}).items():
+            p = k.get("pmc_mean_per_dispatch", {})
+            if name.startswith("gmm_prefilter16_kernel") and p.get("GRBM_GUI_ACTIVE"):
+                busy = p.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 128.0 / p["GRBM_GUI_ACTIVE"]
     return {
         "roofline_prefilter": {"kernel": "gmm_prefilter16_kernel", "bound": "mfma", "achieved": p_flops / (p_ms * 1e-3) / 1e12,
                                "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": p_flops / (p_ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS,
                                "frac_useful": p_useful / (p_ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS,
                                "avg_launch_ms": p_ms, "dtype": "f16 x f16 -> f32", "includes": "feature transpose (0.04 ms)",
+                               "mfma_pipe_busy": busy, "mfma_pipe_busy_source": traffic_source(args, n_frames),
                                "note": "frac counts the padded K = 96 that the MFMAs execute, frac_useful only K = 81; the matrix pipe is "
-                                       "busy 47 % of the cycles, the rest is the mask epilogue's vector issue (DESIGN 4.1)"},
+                                       "busy about half of the cycles (mfma_pipe_busy, from the PMC summary), the rest is the mask "
+                                       "epilogue's vector issue (DESIGN 4.1)"},
         "gmm_step": {"ms": g_ms, "dense_fp64_flops": dense, "dense_fp64_equiv_tflops": dense / (g_ms * 1e-3) / 1e12,
                      "vs_fp64_mfma_peak": dense / (g_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                      "densities_refined_per_pair": prof["refined_densities"] / max(1, prof["refined_pairs"]), "of": args.mix,
