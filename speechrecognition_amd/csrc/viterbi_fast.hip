@@ -443,7 +443,9 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
             const uint32_t o = og[i] & 0xFFFFu;
             if (v == m_we) {  // traceback[t] = the FIRST minimal surviving word end (:199-205): settled by the atomic, written next frame
               atomicMin(&c_widx[par], o);
-              pend = true; pend_o = o; pend_p = slot_of(i); pend_b = nb[i]; pend_v = v;
+              // (a lane may hold several of them: it keeps the one with the smallest original index, the only one that can win)
+              if (!pend || o < pend_o) { pend_o = o; pend_p = slot_of(i); pend_b = nb[i]; pend_v = v; }
+              pend = true;
             }
             if (v + 0.0 + tf == m_we + 0.0 + tf) atomicMin(&ef_nxt[0], o);
             if (v + 0.0 + ts == m_we + 0.0 + ts) atomicMin(&ef_nxt[1], o);

@@ -49,3 +49,50 @@ def test_device_walk_equals_search_and_host_walk_and_rejects_corruption(tmp_path
         w3, o3 = c.recognize(lexh, 150.0, 10.0)
         assert np.array_equal(w3, words) and np.array_equal(o3, woff)
         c.close(); lexh.close()
+
+
+def test_all_words_tie_exactly(tmp_path, oracle_lib):
+    """Every word a clone of the first (its states carry the same densities, accumulator for accumulator): all word hypotheses
+    tie bit for bit in every frame, so everything that is decided by source ORDER is exercised at once -- the boundary candidate
+    against the in-word candidates (first word-end index per class against the slot's own word, Recognizer.cpp:126,143-157), the
+    FIRST minimal surviving word end of traceback[t] (:199-205) when a lane holds several of them (round 3: the lane must
+    keep the one with the smallest original index), padding lanes, type-boundary waves.  300 utterances -> the throughput
+    geometry (256 threads x 4 slots: one lane owns four tied word ends); 3 utterances -> the wide one."""
+    W, M, D = 200, 2, 39
+    lex = synth.make_lexicon(W, 3, 1)
+    spec = synth.make_mixset(lex.n_states, M, D, seed=77)
+    # states: 0 = silence, word w (1..W) owns states 1 + 3 (w - 1) + k; density rows are state-major, M per state
+    for w in range(2, W + 1):
+        for k in range(3):
+            src, dst = (1 + k) * M, (1 + 3 * (w - 1) + k) * M
+            for arr in (spec.mean_acc, spec.var_acc):
+                arr[dst:dst + M] = arr[src:src + M]
+            spec.mean_w[dst:dst + M] = spec.mean_w[src:src + M]
+            spec.var_w[dst:dst + M] = spec.var_w[src:src + M]
+    mp = str(tmp_path / "clones.mix")
+    synth.write_mixset(mp, spec)
+    word_off, automaton, sil = lex.flatten()
+    o = oracle_lib.Oracle(mp, D, lex, tdp=TDP, am_threshold=60.0, word_penalty=10.0)
+    with capi.Model.from_mixset(mp, D) as m:
+        lexh = m.lexicon(word_off, automaton, lex.silence_idx, TDP, sil)
+        for n_utts in (300, 3):
+            feats, off = synth.make_batch(n_utts, 8, 30, D, seed=78 + n_utts)
+            for u in range(0, n_utts, 2):  # half of them speech-like: a few cloned words in a row
+                x = synth.sample_utterance(spec, lex, [3, 150, 77], seed=u)
+                n = min(len(x), int(off[u + 1] - off[u]))
+                feats[int(off[u]):int(off[u]) + n] = x[:n]
+            c = m.upload(feats, off)
+            sc = c.score(capi.GMM_EXACT)
+            assert np.array_equal(sc[:, 1].view(np.uint64), sc[:, 1 + 3 * 57].view(np.uint64))  # the clones do tie
+            for general in (False, True):
+                words, woff, (tbs, tbw, tbb) = c.recognize(lexh, 60.0, 10.0, capi.GMM_EXACT, traceback=True, general_kernel=general)
+                for u in range(0, n_utts, max(1, n_utts // 40)):
+                    x = feats[int(off[u]):int(off[u + 1])]
+                    w, (os_, ow, ob) = o.decode(x, traceback=True)
+                    a = int(off[u]) + u
+                    assert np.array_equal(w, words[int(woff[u]):int(woff[u + 1])]), (n_utts, general, u)
+                    assert np.array_equal(tbw[a:a + len(x) + 1], ow) and np.array_equal(tbb[a:a + len(x) + 1], ob), (n_utts, general, u)
+                    assert np.array_equal(tbs[a:a + len(x) + 1].view(np.uint64), os_.view(np.uint64)), (n_utts, general, u)
+            c.close()
+        lexh.close()
+    o.close()
