@@ -328,8 +328,9 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
         b = n_b < v ? bkp_new : b;
         v = dmin(v, n_b);
         if (kind == kE0S) {  // one-position word: its dead position-1 slot still feeds best_score (:139,155)
+          // (real slots only: a padding lane of this chunk reads state 0, which need not be a one-position word's state)
           const double dead = ((m_we + wp) + ((type & kTFirstSil) ? tf : ts)) + e;
-          my_best = dmin(my_best, dead);
+          my_best = dmin(my_best, og[i] != 0xFFFFFFFFu ? dead : kInfF);
         }
       }
       nv[i] = v; nb[i] = b;

@@ -96,3 +96,48 @@ def test_all_words_tie_exactly(tmp_path, oracle_lib):
             c.close()
         lexh.close()
     o.close()
+
+
+def test_silence_last_in_the_lexicon_padding_lanes_stay_out_of_best(tmp_path, oracle_lib):
+    """Silence as the LAST word: state 0 belongs to an ordinary word.  The padding lanes that fill the one-position-word
+    chunk of the type-sorted net read state 0's emission; their 'dead position-1 slot' candidate (Recognizer.cpp:139,155)
+    must not reach best_score -- it would be a word entry without the word penalty, up to word_penalty below the true best,
+    and the beam of that frame would shrink by as much.  Narrow beam, large penalty: any such shift changes what survives."""
+    W, M, D = 60, 2, 39
+    ws = np.full(W + 1, 3, dtype=np.uint16); ws[-1] = 1
+    wr = np.ones(W + 1, dtype=np.uint16)
+    lex = synth.LexiconSpec(ws, wr, W)
+    spec = synth.make_mixset(lex.n_states, M, D, seed=31)
+    mp = str(tmp_path / "sil_last.mix")
+    synth.write_mixset(mp, spec)
+    word_off, automaton, sil = lex.flatten()
+    assert sil == lex.n_states - 1
+    beam, wp = 25.0, 20.0
+    o = oracle_lib.Oracle(mp, D, lex, tdp=TDP, am_threshold=beam, word_penalty=wp)
+    n_utts = 300
+    feats, off = synth.make_batch(n_utts, 20, 60, D, seed=32)
+    rng = np.random.default_rng(33)
+    for u in range(n_utts):  # word after word without silence in between, word 0 (state 0) often among them
+        seq = [int(w) for w in rng.integers(0, W, size=4)]
+        seq[int(rng.integers(1, 4))] = 0
+        x = np.concatenate([synth.sample_utterance(spec, lex, [w], seed=1000 * u + i, noise=0.6)[2:-2] for i, w in enumerate(seq)])
+        n = min(len(x), int(off[u + 1] - off[u]))
+        feats[int(off[u]):int(off[u]) + n] = x[:n]
+    with capi.Model.from_mixset(mp, D) as m:
+        lexh = m.lexicon(word_off, automaton, lex.silence_idx, TDP, sil)
+        c = m.upload(feats, off)
+        got = {}
+        for general in (False, True):
+            got[general] = c.recognize(lexh, beam, wp, capi.GMM_EXACT, traceback=True, general_kernel=general)
+        (w0, o0, (s0, tw0, tb0)), (w1, o1, (s1, tw1, tb1)) = got[False], got[True]
+        assert np.array_equal(s0.view(np.uint64), s1.view(np.uint64)) and np.array_equal(tw0, tw1) and np.array_equal(tb0, tb1)
+        assert np.array_equal(w0, w1) and np.array_equal(o0, o1)
+        for u in range(0, n_utts, 6):
+            x = feats[int(off[u]):int(off[u + 1])]
+            w, (os_, ow, ob) = o.decode(x, traceback=True)
+            a = int(off[u]) + u
+            assert np.array_equal(w, w0[int(o0[u]):int(o0[u + 1])]), u
+            assert np.array_equal(tw0[a:a + len(x) + 1], ow) and np.array_equal(tb0[a:a + len(x) + 1], ob), u
+            assert np.array_equal(s0[a:a + len(x) + 1].view(np.uint64), os_.view(np.uint64)), u
+        c.close(); lexh.close()
+    o.close()
