@@ -134,6 +134,61 @@ def make_lexicon(n_words, states_per_word=3, reps=1, extra_states_last=0) -> Lex
     return LexiconSpec(ws, wr, 0)
 
 
+@dataclass
+class ExplicitLexicon:
+    """A lexicon given as the arrays sr_lexicon_create takes: any word may be silence, words may share states."""
+
+    word_off: np.ndarray  # [W + 1] u32
+    automaton: np.ndarray  # u16 emission state per position
+    silence_idx: int
+
+    @property
+    def n_words(self):
+        return len(self.word_off) - 1
+
+    @property
+    def n_states(self):
+        return int(self.automaton.max()) + 1
+
+    def flatten(self):
+        return self.word_off, self.automaton, int(self.automaton[self.word_off[self.silence_idx]])
+
+
+def make_ragged_lexicon(n_words, rng) -> ExplicitLexicon:
+    """What Lexicon::add_word permits and make_lexicon never draws: silence anywhere in the word list, words of 1 .. 40 states
+    with or without repetitions side by side (several one-position words among them), now and then a word that is a clone of
+    an earlier one (the same states: every hypothesis of the two ties) or that starts with the silence state."""
+    sil_idx = int(rng.integers(0, n_words + 1))
+    off, aut, s = [0], [], 0
+    words = []
+    for w in range(n_words + 1):
+        if w == sil_idx:
+            st = [s]; s += 1
+            sil_state = st[0]
+            reps = 1
+        else:
+            r = rng.random()
+            if r < 0.12 and any(i != sil_idx for i in range(len(words))):
+                src = int(rng.choice([i for i in range(len(words)) if i != sil_idx]))
+                st, reps = words[src]
+            else:
+                n = int(rng.choice([1, 1, 2, 3, 3, 4, 7, 40]))
+                st = list(range(s, s + n)); s += n
+                reps = int(rng.integers(1, 3))
+        words.append((st, reps))
+    for w, (st, reps) in enumerate(words):
+        if w != sil_idx and w > sil_idx and rng.random() < 0.05:
+            st = [sil_state] + list(st)  # a word that begins in silence (the tdps are keyed on the state, TdpModel.cpp:19-29)
+        for x in st:
+            aut.extend([x] * reps)
+        off.append(len(aut))
+    if max(off[i + 1] - off[i] for i in range(n_words + 1)) < 2:  # sr_lexicon_create: some word with two or more positions
+        aut.append(s); off[-1] += 1
+        if sil_idx == n_words:  # (never lengthen silence: give the word before it the position instead)
+            aut = aut[:-1]; aut.insert(off[-2], s); off[-2] += 1
+    return ExplicitLexicon(np.asarray(off, dtype=np.uint32), np.asarray(aut, dtype=np.uint16), sil_idx)
+
+
 def sietill_lexicon() -> LexiconSpec:
     """The reference's 12-word / 106-state digit lexicon (sietill/Lexicon.cpp:70-85)."""
     ws = np.array([1, 9, 9, 9, 9, 12, 9, 12, 9, 9, 9, 9], dtype=np.uint16)

@@ -141,3 +141,16 @@ def test_silence_last_in_the_lexicon_padding_lanes_stay_out_of_best(tmp_path, or
             assert np.array_equal(s0[a:a + len(x) + 1].view(np.uint64), os_.view(np.uint64)), u
         c.close(); lexh.close()
     o.close()
+
+
+def test_ragged_lexica_sample_of_the_soak(tmp_path, oracle_lib):
+    """A fixed sample of tools/soak_parity.py's ragged cases (synth.make_ragged_lexicon: silence anywhere in the word list,
+    one-position words beside 40-state ones, cloned words, words that begin in silence) through scoring, search with
+    traceback, both aligners and the bigram search, everything against the oracle.  The full soak (hundreds of cases) is a
+    tool, not a test: DESIGN.md section 8 records its counts."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("soak_parity", os.path.join(os.path.dirname(__file__), "..", "tools", "soak_parity.py"))
+    soak = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(soak)
+    for case in range(16):
+        soak.run_case(case, seed0=41, ragged=True, tmp=str(tmp_path))

@@ -1,17 +1,17 @@
 """Randomised soak of the GPU path against the CPU oracle: random lexica / mixtures / dims / beams / utterance sets,
 scores (prefilter, exact) bit-identical, words + tracebacks + alignments identical, bigram search identical.
-usage: python tools/soak_parity.py [n_cases] [seed]"""
+usage: python tools/soak_parity.py [n_cases] [seed] [ragged]   (ragged: synth.make_ragged_lexicon instead of the uniform one)"""
 import os, sys, tempfile, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from speechrecognition_amd import capi, synth
 from oracle import pyoracle
 
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-tmp = tempfile.mkdtemp()
-t_start = time.time()
-for case in range(n_cases):
+
+
+def run_case(case, seed0=0, ragged=False, tmp=None):
+    """One randomised case; raises AssertionError on the first mismatch, returns the case's description."""
+    tmp = tmp or tempfile.mkdtemp()
     rng = np.random.default_rng(seed0 * 100003 + case)
     W = int(rng.choice([2, 5, 17, 60, 300]))
     spw = int(rng.integers(1, 5))
@@ -20,7 +20,8 @@ for case in range(n_cases):
         reps = 2  # (the decoder wants a word with two or more positions: sr_lexicon_create's documented limit)
     D = int(rng.choice([4, 12, 25, 39, 46, 50]))
     Mhi = int(rng.choice([1, 3, 8, 33, 70]))
-    lex = synth.make_lexicon(W, spw, reps)
+    lex = synth.make_ragged_lexicon(W, rng) if ragged else synth.make_lexicon(W, spw, reps)
+    speech = [w for w in range(lex.n_words) if w != lex.silence_idx]
     nm = rng.integers(1, Mhi + 1, size=lex.n_states)
     spec = synth.make_mixset(lex.n_states, nm, D, seed=case, var_floor=float(rng.choice([0.5, 1e-3])))
     mp = os.path.join(tmp, "m.mix")
@@ -31,12 +32,12 @@ for case in range(n_cases):
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
     feats = (float(rng.choice([1.0, 3.0])) * rng.standard_normal((int(off[-1]), D))).astype(np.float32)
     for u in range(0, n_utts, 3):
-        x = synth.sample_utterance(spec, lex, rng.integers(1, lex.n_words, size=2), seed=case + u)[: lens[u]]
+        x = synth.sample_utterance(spec, lex, rng.choice(speech, size=2), seed=case + u)[: lens[u]]
         feats[int(off[u]):int(off[u]) + len(x)] = x
     word_off, automaton, sil = lex.flatten()
     o = pyoracle.Oracle(mp, D, lex, am_threshold=beam)
     want = o.score_matrix(feats)
-    tag = f"case {case}: W={W} spw={spw} reps={reps} D={D} M<={Mhi} beam={beam} utts={n_utts}"
+    tag = f"case {case}: {'ragged ' if ragged else ''}W={W} spw={spw} reps={reps} sil={lex.silence_idx} D={D} M<={Mhi} beam={beam} utts={n_utts}"
     with capi.Model.from_mixset(mp, D) as m:
         corpus = m.upload(feats, off)
         for k in (capi.GMM_PREFILTER, capi.GMM_EXACT):
@@ -52,7 +53,7 @@ for case in range(n_cases):
             a = int(off[u]) + u
             assert np.array_equal(tbw[a:a + len(x) + 1], ow) and np.array_equal(tbb[a:a + len(x) + 1], ob), (tag, "tb", u)
             assert np.array_equal(tbs[a:a + len(x) + 1].view(np.uint64), os_.view(np.uint64)), (tag, "tb score", u)
-            ws = rng.integers(1, lex.n_words, size=2) if lex.n_words > 1 else []
+            ws = rng.choice(speech, size=2) if speech else []
             aut = [sil]
             for w_ in ws:
                 aut += list(automaton[word_off[w_]:word_off[w_ + 1]]) + [sil]
@@ -86,5 +87,16 @@ for case in range(n_cases):
         lexh.close()
         corpus.close()
     o.close()
-    print(f"ok {tag}  [{time.time() - t_start:.0f} s]", flush=True)
-print("soak passed:", n_cases, "cases")
+    return tag
+
+
+if __name__ == "__main__":
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    ragged = len(sys.argv) > 3 and sys.argv[3] == "ragged"
+    tmp = tempfile.mkdtemp()
+    t_start = time.time()
+    for case in range(n_cases):
+        tag = run_case(case, seed0, ragged, tmp)
+        print(f"ok {tag}  [{time.time() - t_start:.0f} s]", flush=True)
+    print("soak passed:", n_cases, "cases")
