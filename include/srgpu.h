@@ -126,12 +126,16 @@ typedef struct {
   double am_threshold; /* "am-threshold", Recognizer.cpp:31 (beam) */
   double word_penalty; /* "word-penalty", Recognizer.cpp:32 */
   int gmm_kernel;      /* SR_GMM_MFMA, SR_GMM_EXACT or SR_GMM_PREFILTER */
-  int flags;           /* 0, or SR_SEARCH_GENERAL_KERNEL (was `reserved`, must be 0 otherwise) */
+  int flags;           /* 0, SR_SEARCH_GENERAL_KERNEL or SR_SEARCH_SLOT_KERNEL (was `reserved`, must be 0 otherwise) */
 } sr_search_params;
 /* Decode every utterance with the general kernel (slots in reference order, sequential boundary replay inline,
  * viterbi_decode.hip) instead of the type-sorted fast kernel: same results, several times slower.  The fast kernel hands
  * an utterance to it by itself when it meets a negative emission cost; this flag is for cross-checking the two. */
 #define SR_SEARCH_GENERAL_KERNEL 1
+/* Lexica whose words all have at most four positions (and at most 3072 words, score rows that fit the LDS twice) are searched
+ * by the word-per-lane kernel (viterbi_words.hip: a word's hypotheses live in registers); this flag keeps them on the
+ * slot-per-lane kernel that serves every other lexicon (viterbi_fast.hip).  Same results; for cross-checking the two. */
+#define SR_SEARCH_SLOT_KERNEL 2
 
 /* ---- decoder: Recognizer::recognize / recognizeSequence_pruned (Recognizer.cpp:38-92, :103-232) ---
  * Scores every frame of the resident corpus and runs the beam Viterbi per utterance, all on the

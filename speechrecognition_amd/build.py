@@ -19,8 +19,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libsrgpu.so")
 SOURCES = ["srgpu_api.cpp", "mixset.cpp", "feeder.cpp", "gmm_mfma.hip", "gmm_exact.hip", "gmm_prefilter.hip", "viterbi_decode.hip",
-           "viterbi_fast.hip", "viterbi_align.hip", "viterbi_bigram.hip", "em_accumulate.hip", "em_finalize.hip"]
-HEADERS = ["kernels.h", "host_util.h", "handles.h", "traceback.h", os.path.join("..", "..", "include", "srgpu.h")]
+           "viterbi_fast.hip", "viterbi_words.hip", "viterbi_align.hip", "viterbi_bigram.hip", "em_accumulate.hip", "em_finalize.hip"]
+HEADERS = ["kernels.h", "host_util.h", "handles.h", "traceback.h", "dpp_util.h", os.path.join("..", "..", "include", "srgpu.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 # these replay the reference's SSE2 operation order and must not contract a*b+c into an FMA
 PER_FILE = {"gmm_exact.hip": ["-ffp-contract=off"], "gmm_prefilter.hip": ["-ffp-contract=off"], "em_accumulate.hip": ["-ffp-contract=off"],

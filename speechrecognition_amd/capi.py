@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("SRGPU_LIB") or os.path.join(HERE, "libsrgpu.so")
 GMM_MFMA, GMM_EXACT, GMM_PREFILTER = 0, 1, 2
 POOL_GLOBAL, POOL_MIXTURE, POOL_NONE = 0, 1, 2
 SEARCH_GENERAL_KERNEL = 1
+SEARCH_SLOT_KERNEL = 2
 SR_ECORRUPT = -7
 
 # every symbol include/srgpu.h declares
@@ -268,11 +269,11 @@ class Corpus:
         _check(lib().sr_score_corpus(self.model.h, self.h, kernel, _ptr(out)))
         return out
 
-    def recognize(self, lexicon, am_threshold, word_penalty, kernel=GMM_PREFILTER, traceback=False, general_kernel=False):
+    def recognize(self, lexicon, am_threshold, word_penalty, kernel=GMM_PREFILTER, traceback=False, general_kernel=False, slot_kernel=False):
         """-> (words u32[], word_off u64[n_utts+1]) [, (tb_score, tb_word, tb_bkp)]"""
         words = np.zeros(max(self.n_frames, 1), dtype=np.uint32)
         woff = np.zeros(self.n_utts + 1, dtype=np.uint64)
-        sp = SearchParams(am_threshold, word_penalty, kernel, SEARCH_GENERAL_KERNEL if general_kernel else 0)
+        sp = SearchParams(am_threshold, word_penalty, kernel, (SEARCH_GENERAL_KERNEL if general_kernel else 0) | (SEARCH_SLOT_KERNEL if slot_kernel else 0))
         tbs = tbw = tbb = None
         if traceback:
             n = self.n_frames + self.n_utts

@@ -1,0 +1,80 @@
+// dpp_util.h -- wave and row reductions with DPP, v_min_f64, LDS ds_min_f64: shared by the search kernels
+// (viterbi_fast.hip, viterbi_words.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace srgpu {
+
+static constexpr double kInfF = __builtin_huge_val();
+
+// ---- DPP helpers --------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK>
+__device__ inline int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);  // lanes without a source keep v
+}
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_d(double v) {
+  return __hiloint2double(dpp_i<CTRL, ROW_MASK>(__double2hiint(v)), dpp_i<CTRL, ROW_MASK>(__double2loint(v)));
+}
+__device__ inline double readlane63_d(double v) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+// v_min_f64 directly: one instruction per reduction step instead of compare + two selects (fmin() would canonicalise
+// its operands first).  Hypothesis scores are never NaN; +inf is an ordinary operand.
+__device__ inline double dmin(double a, double b) {
+  double r;
+  asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ inline uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+// LDS ds_min_f64, no return value (the cell is read after the workgroup barrier)
+__device__ inline void atomic_min_f64_lds(double* cell, double v) {
+  asm volatile("ds_min_f64 %0, %1" : : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)cell), "v"(v) : "memory");
+}
+// full-wave minimum, returned to every lane
+__device__ inline double wave_min_dpp(double v) {
+  v = dmin(v, dpp_d<0xB1, 0xF>(v));    // quad_perm [1,0,3,2]
+  v = dmin(v, dpp_d<0x4E, 0xF>(v));    // quad_perm [2,3,0,1]
+  v = dmin(v, dpp_d<0x141, 0xF>(v));   // row_half_mirror
+  v = dmin(v, dpp_d<0x140, 0xF>(v));   // row_mirror
+  v = dmin(v, dpp_d<0x142, 0xA>(v));   // row_bcast15 -> rows 1, 3
+  v = dmin(v, dpp_d<0x143, 0xC>(v));   // row_bcast31 -> rows 2, 3
+  return readlane63_d(v);
+}
+__device__ inline uint32_t wave_min_u32_dpp(uint32_t v) {
+  v = umin(v, (uint32_t)dpp_i<0xB1, 0xF>((int)v));
+  v = umin(v, (uint32_t)dpp_i<0x4E, 0xF>((int)v));
+  v = umin(v, (uint32_t)dpp_i<0x141, 0xF>((int)v));
+  v = umin(v, (uint32_t)dpp_i<0x140, 0xF>((int)v));
+  v = umin(v, (uint32_t)dpp_i<0x142, 0xA>((int)v));
+  v = umin(v, (uint32_t)dpp_i<0x143, 0xC>((int)v));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// full-wave lexicographic (value, index) minimum, returned to every lane: the minimum value first, then the smallest
+// index among the lanes that hold it
+__device__ inline void wave_min_idx_dpp(double& v, uint32_t& idx) {
+  const double m = wave_min_dpp(v);
+  idx = wave_min_u32_dpp(v == m ? idx : 0xFFFFFFFFu);
+  v = m;
+}
+// the same over a row of 16 lanes, result in every lane of the row (the cross-wave stage: each row holds all <= 16 partials)
+__device__ inline double row_min_dpp(double v) {
+  v = dmin(v, dpp_d<0xB1, 0xF>(v));
+  v = dmin(v, dpp_d<0x4E, 0xF>(v));
+  v = dmin(v, dpp_d<0x141, 0xF>(v));
+  v = dmin(v, dpp_d<0x140, 0xF>(v));
+  return v;
+}
+__device__ inline void row_min_idx_dpp(double& v, uint32_t& idx) {
+  const double m = row_min_dpp(v);
+  uint32_t c = v == m ? idx : 0xFFFFFFFFu;
+  c = umin(c, (uint32_t)dpp_i<0xB1, 0xF>((int)c));
+  c = umin(c, (uint32_t)dpp_i<0x4E, 0xF>((int)c));
+  c = umin(c, (uint32_t)dpp_i<0x141, 0xF>((int)c));
+  c = umin(c, (uint32_t)dpp_i<0x140, 0xF>((int)c));
+  idx = c;
+  v = m;
+}
+
+}  // namespace srgpu

@@ -159,6 +159,9 @@ struct sr_lexicon {
   // type-sorted copy for the fast kernel
   DevBuf<uint32_t> f_state, f_pred, f_orig, f_type, f_word;
   uint32_t f_n = 0, f_init = 0, f_init_end = 0;
+  DevBuf<uint32_t> w_info;   // word-per-lane network (viterbi_words.hip); empty unless every word has <= 4 positions
+  DevBuf<uint2> w_states;
+  uint32_t max_pos = 0;
   bool big = false;                 // more slots than the LDS kernels hold: decode_big_kernel, no type-sorted copy
 };
 

@@ -116,9 +116,17 @@ struct FastNet {
   uint32_t init_slot;           // sorted id of original slot 0
   uint32_t init_is_end;         // original slot 0 is a word end
 };
+// The same network word by word for the word-per-lane kernel (viterbi_words.hip): lexica whose words all have <= 4 positions
+struct WordNet {
+  const uint32_t* info;         // [W] positions (bits 0-2) | silence word (8) | first state is silence (16) | position p's state is silence << (8 + p); null: not built
+  const uint2* states;          // [W] emission state of positions 0..3, 16 bits each
+  uint32_t max_pos;             // longest word
+  uint32_t init_is_end;         // word 0 has one position: the initial hypothesis is a word end
+};
 struct DecodeArgs {
   DecodeNet net;
   FastNet fast;
+  WordNet words;
   const double* scores;         // [frames x ld] dense emission costs of this launch's frames
   uint32_t ld;
   const uint64_t* frame_off;    // [n_utts+1] global frame offsets of the corpus
@@ -134,10 +142,13 @@ struct DecodeArgs {
   uint32_t* out_words;          // utterance u writes its words at out_words[frame_off[u] ...]
   uint32_t* out_count;          // [n_utts_total]
   uint32_t* out_flags;          // [n_utts_total] kFlagSlowPath | kFlagReplay | kFlagCorrupt (traceback.h)
-  uint32_t force_general;       // skip the fast kernel: every utterance goes through decode_kernel<.., REPLAY = true>
+  uint32_t force_general;       // skip the fast kernels: every utterance goes through decode_kernel<.., REPLAY = true>
+  uint32_t force_slots;         // the slot-per-lane kernel (viterbi_fast.hip) even where the word-per-lane kernel applies
 };
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream);       // fast variant, then the replay variant for flagged utterances
 hipError_t launch_decode_fast(const DecodeArgs& a, hipStream_t stream);
+bool decode_words_applies(const DecodeArgs& a);                          // short-word lexicon whose score rows fit the LDS twice
+hipError_t launch_decode_words(const DecodeArgs& a, hipStream_t stream);
 uint32_t decode_max_slots();          // what the LDS-resident kernels hold
 // lexicons beyond that: hypothesis arrays in a global workspace of n_utts * decode_big_workspace(P) bytes
 uint32_t decode_big_max_slots();

@@ -876,8 +876,27 @@ int sr_lexicon_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, c
     f_pred[q] = (k >= 1 ? new_id[p - 1] : q) | ((k >= 2 ? new_id[p - 2] : q) << 16);
     f_orig[q] = p | (base << 16);
   }
+  // ---- word by word for the word-per-lane kernel (viterbi_words.hip): every word at most four positions --------------------
+  std::vector<uint32_t> w_info;
+  std::vector<uint2> w_states;
+  if (max_pos <= 4) {
+    w_info.resize(n_words); w_states.resize(n_words);
+    for (uint32_t w = 0; w < n_words; w++) {
+      const uint32_t b = word_off[w], n = word_off[w + 1] - b;
+      uint32_t f = n, st[4] = {0, 0, 0, 0};
+      if (w == silence_idx) f |= 8u;
+      if (automaton[b] == silence_state) f |= 16u;
+      for (uint32_t k = 0; k < n; k++) {
+        st[k] = automaton[b + k];
+        if (st[k] == silence_state) f |= 1u << (8 + k);
+      }
+      w_info[w] = f;
+      w_states[w] = make_uint2(st[0] | (st[1] << 16), st[2] | (st[3] << 16));
+    }
+  }
   sr_lexicon* l = new sr_lexicon();
   std::unique_ptr<sr_lexicon, int (*)(sr_lexicon*)> own(l, sr_lexicon_destroy);
+  l->max_pos = max_pos;
   l->f_n = Pn; l->f_init = new_id[0]; l->f_init_end = (info[0] >> 18) & 1u; l->big = big;
   l->model = m; l->n_words = n_words; l->n_slots = P; l->silence_idx = silence_idx; l->silence_state = silence_state;
   l->tdp[0] = tdp[0]; l->tdp[1] = tdp[1]; l->tdp[2] = tdp[2];
@@ -885,7 +904,8 @@ int sr_lexicon_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, c
   if ((e = l->slot_info.upload(info.data(), P)) != hipSuccess || (e = l->slot_word.upload(sword.data(), P)) != hipSuccess ||
       (e = l->word_end_slot.upload(wend.data(), n_words)) != hipSuccess || (e = l->f_state.upload(f_state.data(), Pn)) != hipSuccess ||
       (e = l->f_pred.upload(f_pred.data(), Pn)) != hipSuccess || (e = l->f_orig.upload(f_orig.data(), Pn)) != hipSuccess ||
-      (e = l->f_type.upload(f_type.data(), Pn / 64)) != hipSuccess || (e = l->f_word.upload(f_word.data(), Pn)) != hipSuccess)
+      (e = l->f_type.upload(f_type.data(), Pn / 64)) != hipSuccess || (e = l->f_word.upload(f_word.data(), Pn)) != hipSuccess ||
+      (e = l->w_info.upload(w_info.data(), w_info.size())) != hipSuccess || (e = l->w_states.upload(w_states.data(), w_states.size())) != hipSuccess)
     return fail(SR_EHIP, "lexicon upload: %s", hipGetErrorString(e));
   *out = own.release();
   return SR_OK;
@@ -897,7 +917,7 @@ int sr_lexicon_destroy(sr_lexicon* l) {
   if (!l) return SR_OK;
   if (l->model) { (void)hipSetDevice(l->model->device); (void)hipDeviceSynchronize(); }
   l->slot_info.release(); l->slot_word.release(); l->word_end_slot.release();
-  l->f_state.release(); l->f_pred.release(); l->f_orig.release(); l->f_type.release(); l->f_word.release();
+  l->f_state.release(); l->f_pred.release(); l->f_orig.release(); l->f_type.release(); l->f_word.release(); l->w_info.release(); l->w_states.release();
   delete l;
   return SR_OK;
   });
@@ -957,10 +977,13 @@ int sr_recognize_corpus(sr_model* m, sr_corpus* c, sr_lexicon* l, const sr_searc
   da.net.tdp_loop = l->tdp[0]; da.net.tdp_forward = l->tdp[1]; da.net.tdp_skip = l->tdp[2];
   da.fast.n_slots = l->f_n; da.fast.state = l->f_state.p; da.fast.pred = l->f_pred.p; da.fast.orig = l->f_orig.p;
   da.fast.chunk_type = l->f_type.p; da.fast.word = l->f_word.p; da.fast.init_slot = l->f_init; da.fast.init_is_end = l->f_init_end;
+  da.words.info = l->max_pos <= 4 ? l->w_info.p : nullptr; da.words.states = l->w_states.p; da.words.max_pos = l->max_pos;
+  da.words.init_is_end = l->f_init_end;
   da.ld = m->ld; da.frame_off = c->d_frame_off.p; da.utt_order = c->utt_order.p;
   da.am_threshold = p->am_threshold; da.word_penalty = p->word_penalty;
-  if (p->flags & ~SR_SEARCH_GENERAL_KERNEL) return fail(SR_EINVAL, "unknown sr_search_params.flags 0x%x", (unsigned)p->flags);
+  if (p->flags & ~(SR_SEARCH_GENERAL_KERNEL | SR_SEARCH_SLOT_KERNEL)) return fail(SR_EINVAL, "unknown sr_search_params.flags 0x%x", (unsigned)p->flags);
   da.force_general = (p->flags & SR_SEARCH_GENERAL_KERNEL) ? 1u : 0u;
+  da.force_slots = (p->flags & SR_SEARCH_SLOT_KERNEL) ? 1u : 0u;
   da.tb_score = c->tb_score.p; da.tb_word = c->tb_word.p; da.tb_bkp = c->tb_bkp.p;
   da.out_words = c->out_words.p; da.out_count = c->out_count.p; da.out_flags = c->out_flags.p;
 

@@ -526,10 +526,10 @@ hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream) {
   if (a.n_utts == 0) return hipSuccess;
   const uint32_t P = a.net.n_slots;
   const dim3 grid(a.n_utts);
-  // fast variant first (viterbi_fast.hip); then the replay variant, whose workgroups exit at once unless the fast
+  // a fast variant first (viterbi_words.hip for short-word lexica, else viterbi_fast.hip); then the replay variant, whose workgroups exit at once unless the fast
   // one flagged their utterance (negative emission cost)
   if (!a.force_general) {
-    hipError_t e = launch_decode_fast(a, stream);
+    hipError_t e = (!a.force_slots && decode_words_applies(a)) ? launch_decode_words(a, stream) : launch_decode_fast(a, stream);
     if (e != hipSuccess) return e;
   }
 #define SR_LAUNCH(NT, SPT)                                                                                   \

@@ -1,0 +1,325 @@
+// viterbi_words.hip -- the beam Viterbi decoder (Recognizer::recognizeSequence_pruned, sietill/Recognizer.cpp:103-232) for
+// lexica of SHORT words (every word at most four positions: the synthetic configurations of SURVEY 8d are silence + W words of
+// three states).  One workgroup per utterance, one LANE per word (NW words per lane for W > 1024).
+//
+// In a linear whole-word lexicon every in-word transition stays inside its word (loop, forward, skip: Recognizer.cpp:160-186),
+// and the word-boundary transition reaches a word only through the minimum over the surviving word ends (viterbi_decode.hip, the
+// exactness argument; viterbi_fast.hip, the collapsed boundary candidate).  A lane that owns a whole word therefore keeps the
+// word's hypotheses -- score and back pointer per position -- in REGISTERS over the frame loop: what the slot-per-lane kernel
+// (viterbi_fast.hip) moves through LDS per frame, 16 bytes per hypothesis read up to three times and written once, and the
+// barrier that separates those reads from the writes, do not exist here.  Per frame:
+//
+//   A  every lane: emission costs of its positions from the score row in LDS (staged by LDS-DMA one frame ahead), the new
+//      hypotheses from the old ones in registers, in the reference's source order (skip, forward, loop ascending by source
+//      index; a later candidate must be strictly better), the boundary candidate (m_we + word penalty) + tdp + position 0's
+//      emission for positions 0 and 1 (Recognizer.cpp:133-157, :148-151 for the emission quirk);
+//   B  block minimum and word-end minimum: DPP row reduction, four LDS ds_min_f64 per wave;            -- the ONE barrier --
+//   C  prune against best + am_threshold (:194-196), the word-end bookkeeping: traceback[t] = the FIRST minimal surviving
+//      word end (:199-205, LDS atomic min on the original hypothesis index), first word-end index per boundary class for the
+//      tie order of the next frame.
+//
+// Everything that crosses the barrier sits in LDS cells that rotate over THREE frames (written in frame t, read in t or t + 1,
+// reset one barrier before their next use), which is what lets a frame do with one barrier.
+//
+// Same premise as the slot kernel: every emission cost of the utterance is >= 0 (the reference's pre-AM early-out,
+// Recognizer.cpp:143,173, is inert then); an utterance that breaks it is flagged kFlagReplay and redone by
+// decode_kernel<.., REPLAY = true>.  Results are bit-identical to the slot kernel, the general kernel and the oracle; tie
+// order is the reference's hypothesis index word * max_pos + pos, which orders like word_off[word] + pos.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dpp_util.h"
+#include "kernels.h"
+#include "traceback.h"
+
+namespace srgpu {
+
+// word info: bits 0-2 number of positions (0 = padding lane), bit 3 silence word, bit 4 first state is the silence state,
+// bits 8-11 position p's state is the silence state
+static constexpr uint32_t kWSilWord = 8u, kWFirstSil = 16u;
+
+static constexpr uint32_t kWordsCellBytes = 1024;  // minima and first-index cells; the row buffers follow, 1 KB aligned
+
+template <int NW, int NP>
+__global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double* c_best = reinterpret_cast<double*>(smem);                 // [3] block minimum of the frame's new scores, by frame mod 3
+  double* c_we = c_best + 3;                                        // [3] minimum over the word-end hypotheses
+  uint32_t* c_widx = reinterpret_cast<uint32_t*>(c_we + 3);         // [3] first original index among the minimal word ends
+  uint32_t* e_first = c_widx + 3;                                   // [3][4] first word-end original index per boundary class
+  uint32_t* s_bad = e_first + 12;                                   // [1]
+  unsigned char* rows_lds = smem + kWordsCellBytes;
+  const uint32_t tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, n_waves = nt >> 6;
+  const uint32_t row_bytes = a.ld * 8u, row_pad = (row_bytes + 1023u) & ~1023u;
+
+  const uint32_t u = a.utt_order ? a.utt_order[a.utt_first + blockIdx.x] : a.utt_first + blockIdx.x;
+  const uint64_t f0 = a.frame_off[u];
+  const uint32_t T = (uint32_t)(a.frame_off[u + 1] - f0);
+  const double* row0 = a.scores + (f0 - a.frame_base) * a.ld;
+  const uint64_t tb0 = f0 + u;
+  const double tl = a.net.tdp_loop, tf = a.net.tdp_forward, ts = a.net.tdp_skip;
+  const double wp_word = a.word_penalty, thr = a.am_threshold;
+  const uint32_t n_words = a.net.n_words;
+
+  // ---- the lane's words: word tid + k * nt ------------------------------------------------------------------------------
+  uint32_t info[NW], o_end[NW], st[NW][NP];
+  double sc[NW][NP];
+  uint32_t bk[NW][NP];
+#pragma unroll
+  for (int k = 0; k < NW; k++) {
+    const uint32_t w = tid + (uint32_t)k * nt;
+    const bool in = w < n_words;
+    info[k] = in ? a.words.info[w] : 0u;
+    o_end[k] = in ? a.net.word_end_slot[w] : 0u;  // original index of the word's last position
+    const uint2 s4 = in ? a.words.states[w] : make_uint2(0u, 0u);
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+      const uint32_t half = p < 2 ? s4.x : s4.y;
+      st[k][p] = ((half >> (16 * (p & 1))) & 0xFFFFu) * 8u;  // byte offset of the emission cost in the row (0 for unused positions)
+      sc[k][p] = kInfF;
+      bk[k][p] = 0u;
+    }
+  }
+  if (tid < 12) e_first[tid] = 0xFFFFFFFFu;
+  if (tid < 3) { c_best[tid] = kInfF; c_we[tid] = kInfF; c_widx[tid] = 0xFFFFFFFFu; }
+  if (tid == 12) *s_bad = 0;
+  const bool init_is_end = a.words.init_is_end;
+  double m_we = init_is_end ? 0.0 : kInfF;  // minimum over the word ends that survived the previous frame (uniform)
+  if (tid == 0) {
+    sc[0][0] = 0.0;  // initial hypothesis: word 0, position 0, score 0 (Recognizer.cpp:120)
+    a.tb_score[tb0] = 0.0; a.tb_word[tb0] = 0; a.tb_bkp[tb0] = 0;
+  }
+  __syncthreads();
+  if (tid < 4 && init_is_end) e_first[tid] = 0;  // "frame 0": the initial hypothesis is a word end of index 0 in every class
+
+  auto issue_row = [&](uint32_t frame /* 1-based */) {  // row of `frame` -> buffer frame & 1; every wave copies its share of the pieces
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(row0 + (uint64_t)(frame - 1) * a.ld);
+    unsigned char* dst = rows_lds + (frame & 1u) * row_pad;
+    for (uint32_t piece = wave; piece * 1024u < row_bytes; piece += n_waves) {
+      const uint32_t off = piece * 1024u + lane * 16u;
+      if (off < row_bytes)  // (a row is a multiple of 64 bytes; the last piece may be short)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
+                                         (__attribute__((address_space(3))) void*)(dst + piece * 1024u), 16, 0, 0);
+    }
+  };
+  if (T > 0) { issue_row(1); __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0)
+  __syncthreads();
+
+  uint64_t bad = 0;  // lanes that met an emission cost that is not >= 0 (scalar mask, looked at after the last frame)
+  // the lane that may own traceback[t]: it held the word-end minimum of frame t; settled by the atomic, written one barrier later
+  bool pend = false;
+  uint32_t pend_o = 0, pend_w = 0, pend_b = 0;
+  double pend_v = 0.0;
+  bool prev_alive = true;  // frame 0: traceback[0] is written above
+  auto flush_pending = [&](const uint32_t t_prev) {  // t_prev >= 1, after the barrier that follows frame t_prev's atomics
+    if (__any(pend)) {  // wave-uniform, about one wave per frame
+      if (pend && c_widx[t_prev % 3u] == pend_o) {
+        a.tb_score[tb0 + t_prev] = pend_v; a.tb_word[tb0 + t_prev] = (uint16_t)pend_w; a.tb_bkp[tb0 + t_prev] = (uint16_t)pend_b;
+      }
+      pend = false;
+    }
+    // no word end survived: Book(inf, 0, 0), Recognizer.cpp:118,191
+    if (!prev_alive && tid == 0) { a.tb_score[tb0 + t_prev] = kInfF; a.tb_word[tb0 + t_prev] = 0; a.tb_bkp[tb0 + t_prev] = 0; }
+  };
+
+  uint32_t r = 1, r_prev = 0;  // t % 3, (t - 1) % 3
+  for (uint32_t t = 1; t <= T; t++) {
+    const uint32_t bkp_new = (t - 1) & 0xFFFFu;
+    if (t + 1 <= T) issue_row(t + 1);
+    const unsigned char* row_l = rows_lds + (t & 1u) * row_pad;
+    const bool we_in = m_we != kInfF;  // uniform: a word end survived the previous frame -- else every boundary candidate is +inf
+
+    // ---- A: the new hypotheses of the lane's words ---------------------------------------------------------------------
+    double nv[NW][NP];
+    uint32_t nb[NW][NP];
+    uint32_t tie = 0;  // bit 2k + p: the boundary candidate of word k's position p (0 or 1) ties with the in-word minimum
+    double my_best = kInfF, my_we = kInfF;
+    double e[NW][NP];
+#pragma unroll
+    for (int k = 0; k < NW; k++)
+#pragma unroll
+      for (int p = 0; p < NP; p++) e[k][p] = *reinterpret_cast<const double*>(row_l + st[k][p]);
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+      const uint32_t n = info[k] & 7u;
+      const bool sil_word = info[k] & kWSilWord, first_sil = info[k] & kWFirstSil;
+      const double wp = sil_word ? 0.0 : wp_word;
+      const double base_we = m_we + wp;  // cur_hyp->score + word_penalty (:135-140), + tdp below
+#pragma unroll
+      for (int p = NP - 1; p >= 0; p--) {
+        const bool valid = (uint32_t)p < n, end = (uint32_t)p + 1u == n;
+        const bool sil = (info[k] >> (8 + p)) & 1u;
+        const double t_loop = sil ? tf : tl, t_skip = sil ? tf : ts;  // TdpModel.cpp:19-29, keyed on the destination state
+        const double ep = e[k][p];
+        bad |= __ballot(valid && !(ep >= 0.0));
+        double v = kInfF;
+        uint32_t b = 0;
+        if (p >= 2) {  // skip, forward: in source order, a later one must be strictly better
+          const double s2 = (sc[k][p - 2] + t_skip) + ep, s1 = (sc[k][p - 1] + tf) + ep;
+          b = s1 < s2 ? bk[k][p - 1] : bk[k][p - 2];
+          v = dmin(s2, s1);
+        } else if (p == 1) {
+          v = (sc[k][0] + tf) + ep;
+          b = bk[k][0];
+        }
+        {  // loop, unless the source is the word end (word-end hypotheses are expanded across the boundary only, :130-158)
+          const double s0 = end ? kInfF : (sc[k][p] + t_loop) + ep;
+          b = s0 < v ? bk[k][p] : b;
+          v = dmin(v, s0);
+        }
+        if (p <= 1) {
+          // the collapsed word-boundary candidate (+inf while no word end is alive): after the in-word candidates, unless phase C
+          // finds a tie and an earlier word end.  Scored with position 0's emission (Recognizer.cpp:136,148-151)
+          const bool b_skip = p == 1 && !first_sil;
+          const double n_b = (base_we + (b_skip ? ts : tf)) + e[k][0];
+          if (we_in && valid && n_b == v) tie |= 1u << (2 * k + p);
+          b = n_b < v ? bkp_new : b;
+          v = dmin(v, n_b);
+          if (p == 0) {  // one-position word: its dead position-1 hypothesis still feeds best_score (:139,155)
+            const double dead = (base_we + (first_sil ? tf : ts)) + ep;
+            my_best = dmin(my_best, n == 1u ? dead : kInfF);
+          }
+        }
+        v = valid ? v : kInfF;
+        nv[k][p] = v; nb[k][p] = b;
+        my_best = dmin(my_best, v);
+        my_we = dmin(my_we, end ? v : kInfF);
+      }
+    }
+
+    // ---- B: block minima through LDS ds_min_f64 cells, fed by one lane per row of 16 ---------------------------------------
+    my_best = row_min_dpp(my_best);
+    my_we = row_min_dpp(my_we);
+    if ((lane & 15u) == 0) { atomic_min_f64_lds(&c_best[r], my_best); atomic_min_f64_lds(&c_we[r], my_we); }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of the next row have landed; the barrier publishes them
+    __syncthreads();
+
+    // ---- C: prune, word-end bookkeeping ------------------------------------------------------------------------------------
+    const double best = c_best[r], we = c_we[r];
+    const double limit = best + thr;
+    const bool we_alive = !(we > limit) && we != kInfF;
+    if (__ballot(tie != 0)) {  // rare: the boundary source came first where the first minimal word end of the class precedes the word
+      const uint32_t* ef_prev = e_first + 4 * r_prev;  // written in phase C of frame t - 1: complete since this frame's barrier
+#pragma unroll
+      for (int k = 0; k < NW; k++) {
+        const uint32_t n = info[k] & 7u, base = o_end[k] - (n - 1u);
+        const bool sil_word = info[k] & kWSilWord, first_sil = info[k] & kWFirstSil;
+#pragma unroll
+        for (int p = 0; p < 2 && p < NP; p++) {
+          const bool b_skip = p == 1 && !first_sil;
+          const uint32_t cls = (sil_word ? 0u : 2u) + (b_skip ? 1u : 0u);
+          if ((tie >> (2 * k + p) & 1u) && ef_prev[cls] < base) nb[k][p] = bkp_new;  // the in-word candidate had to be strictly better
+        }
+      }
+    }
+    if (t > 1) flush_pending(t - 1);
+    m_we = we_alive ? we : kInfF;
+    prev_alive = we_alive;
+#pragma unroll
+    for (int k = 0; k < NW; k++)
+#pragma unroll
+      for (int p = 0; p < NP; p++) {
+        double v = nv[k][p];
+        if (v > limit) v = kInfF;  // :194-196
+        sc[k][p] = v; bk[k][p] = nb[k][p];
+      }
+    if (we_alive) {  // uniform
+      const double near = m_we + (fabs(m_we) + fabs(wp_word) + fabs(tf) + fabs(ts) + 1.0) * 1e-9;
+      double v_end[NW];
+      uint32_t b_end[NW];
+      uint64_t any_near = 0;
+#pragma unroll
+      for (int k = 0; k < NW; k++) {
+        const uint32_t n = info[k] & 7u;
+        v_end[k] = kInfF; b_end[k] = 0;
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+          if ((uint32_t)p + 1u == n) { v_end[k] = sc[k][p]; b_end[k] = bk[k][p]; }
+        any_near |= __ballot(v_end[k] <= near);
+      }
+      if (any_near) {  // the wave that holds the minimum (about one lane of the block)
+        uint32_t* ef_nxt = e_first + 4 * r;
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+          const double v = v_end[k];
+          if (v <= near) {
+            const uint32_t o = o_end[k];
+            if (v == m_we) {  // traceback[t] = the FIRST minimal surviving word end (:199-205): settled by the atomic, written after the next barrier
+              atomicMin(&c_widx[r], o);
+              // (a lane may hold several of them: it keeps the one with the smallest original index, the only one that can win)
+              if (!pend || o < pend_o) { pend_o = o; pend_w = tid + (uint32_t)k * nt; pend_b = b_end[k]; pend_v = v; }
+              pend = true;
+            }
+            // first word end per boundary class whose candidate (score + word penalty + tdp) equals the minimum's after rounding
+            if (v + 0.0 + tf == m_we + 0.0 + tf) atomicMin(&ef_nxt[0], o);
+            if (v + 0.0 + ts == m_we + 0.0 + ts) atomicMin(&ef_nxt[1], o);
+            if (v + wp_word + tf == m_we + wp_word + tf) atomicMin(&ef_nxt[2], o);
+            if (v + wp_word + ts == m_we + wp_word + ts) atomicMin(&ef_nxt[3], o);
+          }
+        }
+      }
+    }
+    // resets, each one barrier before the cell's next atomics and after its last reads: the minima of frame t + 2 (last read
+    // in phase C of t - 1), the index cells of frame t + 1 (last read in phase C of t - 1 too: flush and tie patch of t - 2's)
+    {
+      const uint32_t r_next = r == 2 ? 0u : r + 1u;
+      if (tid == 0) { c_best[r_prev] = kInfF; c_we[r_prev] = kInfF; c_widx[r_next] = 0xFFFFFFFFu; }  // (t + 2) % 3 == (t - 1) % 3
+      if (tid >= 4 && tid < 8) e_first[4 * r_next + (tid - 4)] = 0xFFFFFFFFu;
+      r_prev = r; r = r_next;
+    }
+  }
+  __syncthreads();
+  if (T > 0) flush_pending(T);
+
+  // the premise failed somewhere (a negative or NaN emission cost): hand the utterance to the replay variant
+  if (bad) *s_bad = 1;
+  __threadfence();
+  __syncthreads();
+  if (*s_bad) {  // workgroup-uniform
+    if (tid == 0) { atomicOr(&a.out_flags[u], kFlagReplay); a.out_count[u] = 0; }
+    return;
+  }
+
+  // ---- traceback (Recognizer.cpp:222-231; guarded walk: traceback.h) ---------------------------------------------------
+  if (tid == 0) {
+    const uint32_t n = walk_traceback(
+        T, a.net.silence_word, a.net.n_words,
+        [&](uint32_t t) -> uint32_t { return __hip_atomic_load(&a.tb_word[tb0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
+        [&](uint32_t t) -> uint32_t { return __hip_atomic_load(&a.tb_bkp[tb0 + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); },
+        a.out_words + f0, T);
+    if (n == kTbCorrupt) atomicOr(&a.out_flags[u], kFlagCorrupt);
+    a.out_count[u] = n == kTbCorrupt ? 0u : n;
+  }
+}
+
+static size_t words_smem(uint32_t ld) { return kWordsCellBytes + 2 * (((size_t)ld * 8 + 1023u) & ~(size_t)1023u); }
+static constexpr size_t kLdsPerWorkgroup = 160 * 1024;
+
+bool decode_words_applies(const DecodeArgs& a) {
+  return a.words.info != nullptr && a.words.max_pos <= 4 && a.net.n_words <= 3 * 1024 && words_smem(a.ld) <= kLdsPerWorkgroup;
+}
+
+hipError_t launch_decode_words(const DecodeArgs& a, hipStream_t stream) {
+  if (a.n_utts == 0) return hipSuccess;
+  if (!decode_words_applies(a)) return hipErrorInvalidValue;
+  const uint32_t W = a.net.n_words;
+  const uint32_t nw = (W + 1023) / 1024;                       // words per lane
+  const uint32_t nt = (((W + nw - 1) / nw) + 63) / 64 * 64;    // lanes, in whole waves
+  const size_t smem = words_smem(a.ld);
+  auto go = [&](auto kernel) {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(a.n_utts), dim3(nt), smem, stream, a);
+    return hipGetLastError();
+  };
+  if (a.words.max_pos <= 3) {
+    if (nw == 1) return go(decode_words_kernel<1, 3>);
+    if (nw == 2) return go(decode_words_kernel<2, 3>);
+    return go(decode_words_kernel<3, 3>);
+  }
+  if (nw == 1) return go(decode_words_kernel<1, 4>);
+  if (nw == 2) return go(decode_words_kernel<2, 4>);
+  return go(decode_words_kernel<3, 4>);
+}
+
+}  // namespace srgpu

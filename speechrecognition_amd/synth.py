@@ -154,10 +154,11 @@ class ExplicitLexicon:
         return self.word_off, self.automaton, int(self.automaton[self.word_off[self.silence_idx]])
 
 
-def make_ragged_lexicon(n_words, rng) -> ExplicitLexicon:
+def make_ragged_lexicon(n_words, rng, short=False) -> ExplicitLexicon:
     """What Lexicon::add_word permits and make_lexicon never draws: silence anywhere in the word list, words of 1 .. 40 states
     with or without repetitions side by side (several one-position words among them), now and then a word that is a clone of
-    an earlier one (the same states: every hypothesis of the two ties) or that starts with the silence state."""
+    an earlier one (the same states: every hypothesis of the two ties) or that starts with the silence state.
+    short: every word has at most four positions (the lexica the word-per-lane search kernel takes)."""
     sil_idx = int(rng.integers(0, n_words + 1))
     off, aut, s = [0], [], 0
     words = []
@@ -172,12 +173,12 @@ def make_ragged_lexicon(n_words, rng) -> ExplicitLexicon:
                 src = int(rng.choice([i for i in range(len(words)) if i != sil_idx]))
                 st, reps = words[src]
             else:
-                n = int(rng.choice([1, 1, 2, 3, 3, 4, 7, 40]))
+                n = int(rng.choice([1, 2, 3, 4] if short else [1, 1, 2, 3, 3, 4, 7, 40]))
                 st = list(range(s, s + n)); s += n
-                reps = int(rng.integers(1, 3))
+                reps = int(rng.integers(1, 3)) if not short or n <= 2 else 1  # short: at most four positions per word
         words.append((st, reps))
     for w, (st, reps) in enumerate(words):
-        if w != sil_idx and w > sil_idx and rng.random() < 0.05:
+        if w != sil_idx and w > sil_idx and rng.random() < 0.05 and (not short or len(st) * reps < 4):
             st = [sil_state] + list(st)  # a word that begins in silence (the tdps are keyed on the state, TdpModel.cpp:19-29)
         for x in st:
             aut.extend([x] * reps)

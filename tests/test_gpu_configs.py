@@ -30,11 +30,16 @@ def test_cfg3_default_pairing_prefilter_plus_fast_decoder(tmp_path, oracle_lib):
         corpus = m.upload(feats, off)
         words, woff, (tbs, tbw, tbb) = corpus.recognize(lexh, 200.0, 10.0, capi.GMM_PREFILTER, traceback=True)
         w2, o2, (s2, ww2, b2) = corpus.recognize(lexh, 200.0, 10.0, capi.GMM_EXACT, traceback=True, general_kernel=True)
+        # three-state words: the default search kernel is the word-per-lane one (viterbi_words.hip); the slot-per-lane kernel
+        # (viterbi_fast.hip, P = 4000 in its 1024 x 4 layout) must agree as well
+        w3, o3, (s3, ww3, b3) = corpus.recognize(lexh, 200.0, 10.0, capi.GMM_PREFILTER, traceback=True, slot_kernel=True)
         corpus.close()
         lexh.close()
     assert len(words) > 288
     assert np.array_equal(words, w2) and np.array_equal(woff, o2)
     assert np.array_equal(tbw, ww2) and np.array_equal(tbb, b2) and np.array_equal(tbs.view(np.uint64), s2.view(np.uint64))
+    assert np.array_equal(words, w3) and np.array_equal(woff, o3)
+    assert np.array_equal(tbw, ww3) and np.array_equal(tbb, b3) and np.array_equal(tbs.view(np.uint64), s3.view(np.uint64))
     o = oracle_lib.Oracle(mp, 39, lex, am_threshold=200.0)
     for u in (0, 1, 37, 100, 143, 200, 286, 287):
         x = feats[int(off[u]):int(off[u + 1])]

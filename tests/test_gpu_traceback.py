@@ -21,8 +21,8 @@ def test_device_walk_equals_search_and_host_walk_and_rejects_corruption(tmp_path
     with capi.Model.from_mixset(mp, 39) as m:
         lexh = m.lexicon(word_off, automaton, lex.silence_idx, TDP, sil)
         c = m.upload(feats, off)
-        for general in (False, True):
-            words, woff, (tbs, tbw, tbb) = c.recognize(lexh, 150.0, 10.0, capi.GMM_PREFILTER, traceback=True, general_kernel=general)
+        for general, slots in ((False, False), (False, True), (True, False)):  # word-per-lane, slot-per-lane, general kernel
+            words, woff, (tbs, tbw, tbb) = c.recognize(lexh, 150.0, 10.0, capi.GMM_PREFILTER, traceback=True, general_kernel=general, slot_kernel=slots)
             assert len(words) > 70
             w2, o2 = c.retrace(lexh, tbw, tbb)          # the device walker alone
             assert np.array_equal(w2, words) and np.array_equal(o2, woff)
@@ -84,15 +84,15 @@ def test_all_words_tie_exactly(tmp_path, oracle_lib):
             c = m.upload(feats, off)
             sc = c.score(capi.GMM_EXACT)
             assert np.array_equal(sc[:, 1].view(np.uint64), sc[:, 1 + 3 * 57].view(np.uint64))  # the clones do tie
-            for general in (False, True):
-                words, woff, (tbs, tbw, tbb) = c.recognize(lexh, 60.0, 10.0, capi.GMM_EXACT, traceback=True, general_kernel=general)
+            for general, slots in ((False, False), (False, True), (True, False)):  # word-per-lane, slot-per-lane, general kernel
+                words, woff, (tbs, tbw, tbb) = c.recognize(lexh, 60.0, 10.0, capi.GMM_EXACT, traceback=True, general_kernel=general, slot_kernel=slots)
                 for u in range(0, n_utts, max(1, n_utts // 40)):
                     x = feats[int(off[u]):int(off[u + 1])]
                     w, (os_, ow, ob) = o.decode(x, traceback=True)
                     a = int(off[u]) + u
-                    assert np.array_equal(w, words[int(woff[u]):int(woff[u + 1])]), (n_utts, general, u)
-                    assert np.array_equal(tbw[a:a + len(x) + 1], ow) and np.array_equal(tbb[a:a + len(x) + 1], ob), (n_utts, general, u)
-                    assert np.array_equal(tbs[a:a + len(x) + 1].view(np.uint64), os_.view(np.uint64)), (n_utts, general, u)
+                    assert np.array_equal(w, words[int(woff[u]):int(woff[u + 1])]), (n_utts, general, slots, u)
+                    assert np.array_equal(tbw[a:a + len(x) + 1], ow) and np.array_equal(tbb[a:a + len(x) + 1], ob), (n_utts, general, slots, u)
+                    assert np.array_equal(tbs[a:a + len(x) + 1].view(np.uint64), os_.view(np.uint64)), (n_utts, general, slots, u)
             c.close()
         lexh.close()
     o.close()
@@ -127,11 +127,13 @@ def test_silence_last_in_the_lexicon_padding_lanes_stay_out_of_best(tmp_path, or
         lexh = m.lexicon(word_off, automaton, lex.silence_idx, TDP, sil)
         c = m.upload(feats, off)
         got = {}
-        for general in (False, True):
-            got[general] = c.recognize(lexh, beam, wp, capi.GMM_EXACT, traceback=True, general_kernel=general)
-        (w0, o0, (s0, tw0, tb0)), (w1, o1, (s1, tw1, tb1)) = got[False], got[True]
-        assert np.array_equal(s0.view(np.uint64), s1.view(np.uint64)) and np.array_equal(tw0, tw1) and np.array_equal(tb0, tb1)
-        assert np.array_equal(w0, w1) and np.array_equal(o0, o1)
+        for which, (general, slots) in enumerate(((False, False), (False, True), (True, False))):  # word-per-lane, slot-per-lane, general
+            got[which] = c.recognize(lexh, beam, wp, capi.GMM_EXACT, traceback=True, general_kernel=general, slot_kernel=slots)
+        w0, o0, (s0, tw0, tb0) = got[0]
+        for which in (1, 2):
+            w1, o1, (s1, tw1, tb1) = got[which]
+            assert np.array_equal(s0.view(np.uint64), s1.view(np.uint64)) and np.array_equal(tw0, tw1) and np.array_equal(tb0, tb1), which
+            assert np.array_equal(w0, w1) and np.array_equal(o0, o1), which
         for u in range(0, n_utts, 6):
             x = feats[int(off[u]):int(off[u + 1])]
             w, (os_, ow, ob) = o.decode(x, traceback=True)
@@ -154,3 +156,5 @@ def test_ragged_lexica_sample_of_the_soak(tmp_path, oracle_lib):
     spec.loader.exec_module(soak)
     for case in range(16):
         soak.run_case(case, seed0=41, ragged=True, tmp=str(tmp_path))
+    for case in range(16):  # words of one to four positions only: the word-per-lane kernel, checked against the slot kernel too
+        soak.run_case(case, seed0=47, ragged="short", tmp=str(tmp_path))

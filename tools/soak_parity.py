@@ -1,6 +1,7 @@
 """Randomised soak of the GPU path against the CPU oracle: random lexica / mixtures / dims / beams / utterance sets,
 scores (prefilter, exact) bit-identical, words + tracebacks + alignments identical, bigram search identical.
-usage: python tools/soak_parity.py [n_cases] [seed] [ragged]   (ragged: synth.make_ragged_lexicon instead of the uniform one)"""
+usage: python tools/soak_parity.py [n_cases] [seed] [ragged|short]   (synth.make_ragged_lexicon instead of the uniform lexicon;
+short: words of one to four positions -- the word-per-lane search kernel, cross-checked against the slot-per-lane kernel)"""
 import os, sys, tempfile, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -12,15 +13,21 @@ from oracle import pyoracle
 def run_case(case, seed0=0, ragged=False, tmp=None):
     """One randomised case; raises AssertionError on the first mismatch, returns the case's description."""
     tmp = tmp or tempfile.mkdtemp()
+    if ragged is True:
+        ragged = "ragged"
     rng = np.random.default_rng(seed0 * 100003 + case)
     W = int(rng.choice([2, 5, 17, 60, 300]))
+    if ragged == "short" and rng.random() < 0.15:
+        W = int(rng.choice([1100, 2300]))  # two and three words per lane
     spw = int(rng.integers(1, 5))
     reps = int(rng.integers(1, 3))
     if spw * reps < 2:
         reps = 2  # (the decoder wants a word with two or more positions: sr_lexicon_create's documented limit)
     D = int(rng.choice([4, 12, 25, 39, 46, 50]))
     Mhi = int(rng.choice([1, 3, 8, 33, 70]))
-    lex = synth.make_ragged_lexicon(W, rng) if ragged else synth.make_lexicon(W, spw, reps)
+    if W >= 1000:
+        Mhi = min(Mhi, 3)
+    lex = synth.make_ragged_lexicon(W, rng, short=ragged == "short") if ragged else synth.make_lexicon(W, spw, reps)
     speech = [w for w in range(lex.n_words) if w != lex.silence_idx]
     nm = rng.integers(1, Mhi + 1, size=lex.n_states)
     spec = synth.make_mixset(lex.n_states, nm, D, seed=case, var_floor=float(rng.choice([0.5, 1e-3])))
@@ -28,6 +35,8 @@ def run_case(case, seed0=0, ragged=False, tmp=None):
     synth.write_mixset(mp, spec)
     beam = float(rng.choice([15.0, 60.0, 200.0, 1e9]))
     n_utts = int(rng.choice([1, 3, 9, 140, 300]))
+    if W >= 1000:  # (keeps the oracle's dense score matrix of the case within seconds)
+        n_utts = min(n_utts, 9)
     lens = rng.integers(1, 40, size=n_utts)
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
     feats = (float(rng.choice([1.0, 3.0])) * rng.standard_normal((int(off[-1]), D))).astype(np.float32)
@@ -37,7 +46,7 @@ def run_case(case, seed0=0, ragged=False, tmp=None):
     word_off, automaton, sil = lex.flatten()
     o = pyoracle.Oracle(mp, D, lex, am_threshold=beam)
     want = o.score_matrix(feats)
-    tag = f"case {case}: {'ragged ' if ragged else ''}W={W} spw={spw} reps={reps} sil={lex.silence_idx} D={D} M<={Mhi} beam={beam} utts={n_utts}"
+    tag = f"case {case}: {(ragged + ' ') if ragged else ''}W={W} spw={spw} reps={reps} sil={lex.silence_idx} D={D} M<={Mhi} beam={beam} utts={n_utts}"
     with capi.Model.from_mixset(mp, D) as m:
         corpus = m.upload(feats, off)
         for k in (capi.GMM_PREFILTER, capi.GMM_EXACT):
@@ -45,6 +54,10 @@ def run_case(case, seed0=0, ragged=False, tmp=None):
             assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (tag, "scores", k)
         lexh = m.lexicon(word_off, automaton, lex.silence_idx, (3.0, 0.0, 30.0), sil)
         words, woff, (tbs, tbw, tbb) = corpus.recognize(lexh, beam, 10.0, capi.GMM_PREFILTER, traceback=True)
+        if max(np.diff(word_off.astype(np.int64))) <= 4:  # the word-per-lane kernel ran: the slot-per-lane kernel must agree
+            w_s, o_s, (s_s, tw_s, tb_s) = corpus.recognize(lexh, beam, 10.0, capi.GMM_PREFILTER, traceback=True, slot_kernel=True)
+            assert np.array_equal(w_s, words) and np.array_equal(o_s, woff) and np.array_equal(tw_s, tbw) and np.array_equal(tb_s, tbb), (tag, "slot kernel")
+            assert np.array_equal(s_s.view(np.uint64), tbs.view(np.uint64)), (tag, "slot kernel scores")
         auts, ok_al = [], True
         for u in range(n_utts):
             x = feats[int(off[u]):int(off[u + 1])]
@@ -93,7 +106,7 @@ def run_case(case, seed0=0, ragged=False, tmp=None):
 if __name__ == "__main__":
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    ragged = len(sys.argv) > 3 and sys.argv[3] == "ragged"
+    ragged = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] in ("ragged", "short") else False
     tmp = tempfile.mkdtemp()
     t_start = time.time()
     for case in range(n_cases):
