@@ -161,7 +161,9 @@ struct sr_lexicon {
   uint32_t f_n = 0, f_init = 0, f_init_end = 0;
   DevBuf<uint32_t> w_info;   // word-per-lane network (viterbi_words.hip); empty unless every word has <= 4 positions
   DevBuf<uint2> w_states;
-  uint32_t max_pos = 0;
+  DevBuf<uint32_t> w_order;
+  uint32_t w_plain_len = 0;  // 0: no word-per-lane network
+  uint32_t w_nw = 0, w_nt = 0, w_general = 0;
   bool big = false;                 // more slots than the LDS kernels hold: decode_big_kernel, no type-sorted copy
 };
 

@@ -120,7 +120,10 @@ struct FastNet {
 struct WordNet {
   const uint32_t* info;         // [W] positions (bits 0-2) | silence word (8) | first state is silence (16) | position p's state is silence << (8 + p); null: not built
   const uint2* states;          // [W] emission state of positions 0..3, 16 bits each
-  uint32_t max_pos;             // longest word
+  const uint32_t* order;        // [nw * nt] word of lane slot tid + k * nt; every group of 64 slots holds one kind of word, 0xFFFFFFFF = padding
+  uint32_t nw, nt;              // words per lane, lanes per workgroup (whole waves)
+  uint32_t plain_len;           // positions of a plain word (2, 3 or 4): the commonest length among the words without silence flags
+  uint32_t has_general;         // some word is neither plain nor a one-position word
   uint32_t init_is_end;         // word 0 has one position: the initial hypothesis is a word end
 };
 struct DecodeArgs {
@@ -148,6 +151,7 @@ struct DecodeArgs {
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream);       // fast variant, then the replay variant for flagged utterances
 hipError_t launch_decode_fast(const DecodeArgs& a, hipStream_t stream);
 bool decode_words_applies(const DecodeArgs& a);                          // short-word lexicon whose score rows fit the LDS twice
+uint32_t decode_words_max_words();
 hipError_t launch_decode_words(const DecodeArgs& a, hipStream_t stream);
 uint32_t decode_max_slots();          // what the LDS-resident kernels hold
 // lexicons beyond that: hypothesis arrays in a global workspace of n_utts * decode_big_workspace(P) bytes

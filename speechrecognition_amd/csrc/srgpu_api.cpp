@@ -877,10 +877,12 @@ int sr_lexicon_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, c
     f_orig[q] = p | (base << 16);
   }
   // ---- word by word for the word-per-lane kernel (viterbi_words.hip): every word at most four positions --------------------
-  std::vector<uint32_t> w_info;
+  std::vector<uint32_t> w_info, w_order;
   std::vector<uint2> w_states;
-  if (max_pos <= 4) {
+  uint32_t plain_len = 0, w_nw = 0, w_nt = 0, w_general = 0;
+  if (max_pos <= 4 && n_words <= decode_words_max_words()) {
     w_info.resize(n_words); w_states.resize(n_words);
+    uint32_t hist[5] = {0, 0, 0, 0, 0};
     for (uint32_t w = 0; w < n_words; w++) {
       const uint32_t b = word_off[w], n = word_off[w + 1] - b;
       uint32_t f = n, st[4] = {0, 0, 0, 0};
@@ -892,11 +894,44 @@ int sr_lexicon_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, c
       }
       w_info[w] = f;
       w_states[w] = make_uint2(st[0] | (st[1] << 16), st[2] | (st[3] << 16));
+      if (f == n) hist[n]++;  // no flags
+    }
+    // plain words: the commonest flag-free length of 2..4 positions.  Every kind fills whole groups of 64 lane slots; slot
+    // s = tid + k * nt belongs to group s / 64 = k * n_waves + wave.  Plain and single groups are dealt to the first waves, nw
+    // per wave; a general group -- three times the instructions of a plain one -- gets a wave of its own (its other groups
+    // stay empty), because a frame lasts as long as its heaviest wave (viterbi_words.hip).
+    plain_len = 3;
+    for (uint32_t n = 2; n <= 4; n++) if (hist[n] > hist[plain_len]) plain_len = n;
+    std::vector<uint32_t> kinds[3];  // plain, single, general
+    for (uint32_t w = 0; w < n_words; w++)
+      kinds[w_info[w] == plain_len ? 0 : (w_info[w] & 7u) == 1u ? 1 : 2].push_back(w);
+    const uint32_t g_plain = ((uint32_t)kinds[0].size() + 63) / 64, g_single = ((uint32_t)kinds[1].size() + 63) / 64,
+                   g_gen = ((uint32_t)kinds[2].size() + 63) / 64;
+    w_general = g_gen ? 1u : 0u;
+    // words per lane: the fewest that leave a workgroup of at most 8 waves -- two of them share a CU then (128 registers per
+    // lane each), and while one waits at its barrier the other computes --, else the fewest that fit 16 waves
+    auto waves_for = [&](uint32_t nw) { return (g_plain + g_single + nw - 1) / nw + g_gen; };
+    uint32_t waves = 0;
+    for (w_nw = 1; w_nw <= 3 && waves_for(w_nw) > 8; w_nw++) {}
+    if (w_nw > 3) for (w_nw = 1; w_nw <= 3 && waves_for(w_nw) > 16; w_nw++) {}
+    if (w_nw <= 3) {
+      waves = waves_for(w_nw);
+      w_nt = waves * 64;
+      w_order.assign((size_t)w_nw * w_nt, 0xFFFFFFFFu);
+      auto put_group = [&](uint32_t wave, uint32_t k, const std::vector<uint32_t>& words, uint32_t g) {
+        for (uint32_t i = 0; i < 64 && (size_t)g * 64 + i < words.size(); i++) w_order[(size_t)k * w_nt + wave * 64 + i] = words[(size_t)g * 64 + i];
+      };
+      uint32_t seq = 0;  // plain groups, then single groups: wave seq / nw, slot row seq % nw
+      for (uint32_t g = 0; g < g_plain; g++, seq++) put_group(seq / w_nw, seq % w_nw, kinds[0], g);
+      for (uint32_t g = 0; g < g_single; g++, seq++) put_group(seq / w_nw, seq % w_nw, kinds[1], g);
+      for (uint32_t g = 0; g < g_gen; g++) put_group(waves - g_gen + g, 0, kinds[2], g);
+    } else {
+      plain_len = 0;  // more groups than a workgroup has room for: the slot-per-lane kernel
     }
   }
   sr_lexicon* l = new sr_lexicon();
   std::unique_ptr<sr_lexicon, int (*)(sr_lexicon*)> own(l, sr_lexicon_destroy);
-  l->max_pos = max_pos;
+  l->w_plain_len = plain_len; l->w_nw = w_nw; l->w_nt = w_nt; l->w_general = w_general;
   l->f_n = Pn; l->f_init = new_id[0]; l->f_init_end = (info[0] >> 18) & 1u; l->big = big;
   l->model = m; l->n_words = n_words; l->n_slots = P; l->silence_idx = silence_idx; l->silence_state = silence_state;
   l->tdp[0] = tdp[0]; l->tdp[1] = tdp[1]; l->tdp[2] = tdp[2];
@@ -905,7 +940,8 @@ int sr_lexicon_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, c
       (e = l->word_end_slot.upload(wend.data(), n_words)) != hipSuccess || (e = l->f_state.upload(f_state.data(), Pn)) != hipSuccess ||
       (e = l->f_pred.upload(f_pred.data(), Pn)) != hipSuccess || (e = l->f_orig.upload(f_orig.data(), Pn)) != hipSuccess ||
       (e = l->f_type.upload(f_type.data(), Pn / 64)) != hipSuccess || (e = l->f_word.upload(f_word.data(), Pn)) != hipSuccess ||
-      (e = l->w_info.upload(w_info.data(), w_info.size())) != hipSuccess || (e = l->w_states.upload(w_states.data(), w_states.size())) != hipSuccess)
+      (e = l->w_info.upload(w_info.data(), w_info.size())) != hipSuccess || (e = l->w_states.upload(w_states.data(), w_states.size())) != hipSuccess ||
+      (e = l->w_order.upload(w_order.data(), w_order.size())) != hipSuccess)
     return fail(SR_EHIP, "lexicon upload: %s", hipGetErrorString(e));
   *out = own.release();
   return SR_OK;
@@ -917,7 +953,7 @@ int sr_lexicon_destroy(sr_lexicon* l) {
   if (!l) return SR_OK;
   if (l->model) { (void)hipSetDevice(l->model->device); (void)hipDeviceSynchronize(); }
   l->slot_info.release(); l->slot_word.release(); l->word_end_slot.release();
-  l->f_state.release(); l->f_pred.release(); l->f_orig.release(); l->f_type.release(); l->f_word.release(); l->w_info.release(); l->w_states.release();
+  l->f_state.release(); l->f_pred.release(); l->f_orig.release(); l->f_type.release(); l->f_word.release(); l->w_info.release(); l->w_states.release(); l->w_order.release();
   delete l;
   return SR_OK;
   });
@@ -977,7 +1013,8 @@ int sr_recognize_corpus(sr_model* m, sr_corpus* c, sr_lexicon* l, const sr_searc
   da.net.tdp_loop = l->tdp[0]; da.net.tdp_forward = l->tdp[1]; da.net.tdp_skip = l->tdp[2];
   da.fast.n_slots = l->f_n; da.fast.state = l->f_state.p; da.fast.pred = l->f_pred.p; da.fast.orig = l->f_orig.p;
   da.fast.chunk_type = l->f_type.p; da.fast.word = l->f_word.p; da.fast.init_slot = l->f_init; da.fast.init_is_end = l->f_init_end;
-  da.words.info = l->max_pos <= 4 ? l->w_info.p : nullptr; da.words.states = l->w_states.p; da.words.max_pos = l->max_pos;
+  da.words.info = l->w_plain_len ? l->w_info.p : nullptr; da.words.states = l->w_states.p; da.words.order = l->w_order.p;
+  da.words.plain_len = l->w_plain_len; da.words.nw = l->w_nw; da.words.nt = l->w_nt; da.words.has_general = l->w_general;
   da.words.init_is_end = l->f_init_end;
   da.ld = m->ld; da.frame_off = c->d_frame_off.p; da.utt_order = c->utt_order.p;
   da.am_threshold = p->am_threshold; da.word_penalty = p->word_penalty;

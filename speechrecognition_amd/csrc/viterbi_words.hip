@@ -36,12 +36,27 @@ namespace srgpu {
 
 // word info: bits 0-2 number of positions (0 = padding lane), bit 3 silence word, bit 4 first state is the silence state,
 // bits 8-11 position p's state is the silence state
-static constexpr uint32_t kWSilWord = 8u, kWFirstSil = 16u;
+static constexpr uint32_t kWSilWord = 8u, kWFirstSil = 16u, kWSilStates = 0xF00u;
 
 static constexpr uint32_t kWordsCellBytes = 1024;  // minima and first-index cells; the row buffers follow, 1 KB aligned
 
-template <int NW, int NP>
+// Lanes take their words from an ORDER the host chose (srgpu_api.cpp: build_word_order).  A (wave, k) GROUP of 64 word slots
+// holds words of one kind -- the host pads every kind to whole groups -- and runs that kind's code:
+//   plain    exactly L positions, not the silence word, no silence state: every transition penalty a scalar, the role of
+//            every position known at compile time -- a third of the general path's instructions.  In SURVEY 8d's lexica
+//            every word but silence (and cfg5's one four-state word) is plain;
+//   single   one-position words (silence): the boundary candidate and the dead position-1 hypothesis, nothing else;
+//   general  anything of up to four positions, all decisions per lane (template GEN: compiled in only for lexica that have
+//            such words -- its registers would set the kernel's budget); the host gives a general group a wave of its own;
+//   skip     padding only.
+// A frame lasts as long as its slowest wave (the barrier), so what counts is the instruction count of the heaviest wave.
+// Padding lanes of a plain or single group read a +inf emission cost that sits behind the row in LDS: every candidate of theirs
+// is +inf without a select.
+enum : uint32_t { kGSkip = 0, kGPlain = 1, kGSingle = 2, kGGeneral = 3 };
+
+template <int NW, int L, bool GEN>
 __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
+  constexpr int NPA = GEN ? 4 : L;  // positions a lane keeps per word
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* c_best = reinterpret_cast<double*>(smem);                 // [3] block minimum of the frame's new scores, by frame mod 3
   double* c_we = c_best + 3;                                        // [3] minimum over the word-end hypotheses
@@ -50,7 +65,7 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
   uint32_t* s_bad = e_first + 12;                                   // [1]
   unsigned char* rows_lds = smem + kWordsCellBytes;
   const uint32_t tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, n_waves = nt >> 6;
-  const uint32_t row_bytes = a.ld * 8u, row_pad = (row_bytes + 1023u) & ~1023u;
+  const uint32_t row_bytes = a.ld * 8u, row_pad = (row_bytes + 16u + 1023u) & ~1023u;  // row, then the +inf cell
 
   const uint32_t u = a.utt_order ? a.utt_order[a.utt_first + blockIdx.x] : a.utt_first + blockIdx.x;
   const uint64_t f0 = a.frame_off[u];
@@ -59,36 +74,42 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
   const uint64_t tb0 = f0 + u;
   const double tl = a.net.tdp_loop, tf = a.net.tdp_forward, ts = a.net.tdp_skip;
   const double wp_word = a.word_penalty, thr = a.am_threshold;
-  const uint32_t n_words = a.net.n_words;
 
-  // ---- the lane's words: word tid + k * nt ------------------------------------------------------------------------------
-  uint32_t info[NW], o_end[NW], st[NW][NP];
-  double sc[NW][NP];
-  uint32_t bk[NW][NP];
+  // ---- the lane's words: slot tid + k * nt of the host's order ---------------------------------------------------------------
+  uint32_t word[NW], info[NW], o_end[NW], st[NW][NPA], kind[NW];
+  uint64_t real[NW];  // lanes of the group that hold a word
+  double sc[NW][NPA];
+  uint32_t bk[NW][NPA];
 #pragma unroll
   for (int k = 0; k < NW; k++) {
-    const uint32_t w = tid + (uint32_t)k * nt;
-    const bool in = w < n_words;
+    const uint32_t w = a.words.order[tid + (uint32_t)k * nt];
+    const bool in = w != 0xFFFFFFFFu;
+    word[k] = w;
     info[k] = in ? a.words.info[w] : 0u;
     o_end[k] = in ? a.net.word_end_slot[w] : 0u;  // original index of the word's last position
     const uint2 s4 = in ? a.words.states[w] : make_uint2(0u, 0u);
 #pragma unroll
-    for (int p = 0; p < NP; p++) {
+    for (int p = 0; p < NPA; p++) {
       const uint32_t half = p < 2 ? s4.x : s4.y;
-      st[k][p] = ((half >> (16 * (p & 1))) & 0xFFFFu) * 8u;  // byte offset of the emission cost in the row (0 for unused positions)
+      // byte offset of the emission cost in the row; padding lanes: the +inf cell behind the row
+      st[k][p] = in ? ((half >> (16 * (p & 1))) & 0xFFFFu) * 8u : row_bytes;
       sc[k][p] = kInfF;
       bk[k][p] = 0u;
     }
+    if (w == 0) sc[k][0] = 0.0;  // initial hypothesis: word 0, position 0, score 0 (Recognizer.cpp:120)
+    real[k] = __ballot(in);
+    const uint32_t flags = info[k] & (7u | kWSilWord | kWFirstSil | kWSilStates);
+    kind[k] = real[k] == 0 ? kGSkip : __all(!in || flags == (uint32_t)L) ? kGPlain : __all(!in || (info[k] & 7u) == 1u) ? kGSingle : kGGeneral;
   }
   if (tid < 12) e_first[tid] = 0xFFFFFFFFu;
   if (tid < 3) { c_best[tid] = kInfF; c_we[tid] = kInfF; c_widx[tid] = 0xFFFFFFFFu; }
   if (tid == 12) *s_bad = 0;
+  // (Fetching rows two frames ahead into three buffers was measured: 3.31 ms per step against 2.99 with the same geometry -- the
+  // frame does not wait for its row; and the third buffer costs the second workgroup per CU, which is worth 2.99 -> 2.24 ms.)
+  if (tid < 2) *reinterpret_cast<double*>(rows_lds + tid * row_pad + row_bytes) = kInfF;
   const bool init_is_end = a.words.init_is_end;
   double m_we = init_is_end ? 0.0 : kInfF;  // minimum over the word ends that survived the previous frame (uniform)
-  if (tid == 0) {
-    sc[0][0] = 0.0;  // initial hypothesis: word 0, position 0, score 0 (Recognizer.cpp:120)
-    a.tb_score[tb0] = 0.0; a.tb_word[tb0] = 0; a.tb_bkp[tb0] = 0;
-  }
+  if (tid == 0) { a.tb_score[tb0] = 0.0; a.tb_word[tb0] = 0; a.tb_bkp[tb0] = 0; }
   __syncthreads();
   if (tid < 4 && init_is_end) e_first[tid] = 0;  // "frame 0": the initial hypothesis is a word end of index 0 in every class
 
@@ -127,63 +148,115 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
     const uint32_t bkp_new = (t - 1) & 0xFFFFu;
     if (t + 1 <= T) issue_row(t + 1);
     const unsigned char* row_l = rows_lds + (t & 1u) * row_pad;
-    const bool we_in = m_we != kInfF;  // uniform: a word end survived the previous frame -- else every boundary candidate is +inf
+    const uint64_t we_in = m_we != kInfF ? ~0ull : 0ull;  // uniform: a word end survived the previous frame -- else every boundary candidate is +inf
+    // the collapsed word-boundary candidate of a plain word before its emission cost: cur_hyp->score + word_penalty + tdp
+    // (Recognizer.cpp:135-140); forward into position 0, skip into position 1 -- the same in every lane
+    const double cb_f = (m_we + wp_word) + tf, cb_s = (m_we + wp_word) + ts;
 
-    // ---- A: the new hypotheses of the lane's words ---------------------------------------------------------------------
-    double nv[NW][NP];
-    uint32_t nb[NW][NP];
-    uint32_t tie = 0;  // bit 2k + p: the boundary candidate of word k's position p (0 or 1) ties with the in-word minimum
+    // ---- A: the new hypotheses of the lane's words, in place -- position p's sources are p, p - 1, p - 2: descending p -------
+    // tie[k][p]: lanes where the boundary candidate of word k's position p (0 or 1) ties with the in-word minimum (scalar masks)
+    uint64_t tie[NW][2];
     double my_best = kInfF, my_we = kInfF;
-    double e[NW][NP];
-#pragma unroll
-    for (int k = 0; k < NW; k++)
-#pragma unroll
-      for (int p = 0; p < NP; p++) e[k][p] = *reinterpret_cast<const double*>(row_l + st[k][p]);
+    double e[NW][NPA];
 #pragma unroll
     for (int k = 0; k < NW; k++) {
-      const uint32_t n = info[k] & 7u;
-      const bool sil_word = info[k] & kWSilWord, first_sil = info[k] & kWFirstSil;
-      const double wp = sil_word ? 0.0 : wp_word;
-      const double base_we = m_we + wp;  // cur_hyp->score + word_penalty (:135-140), + tdp below
+      tie[k][0] = tie[k][1] = 0;
+      if (kind[k] == kGSkip) continue;
 #pragma unroll
-      for (int p = NP - 1; p >= 0; p--) {
-        const bool valid = (uint32_t)p < n, end = (uint32_t)p + 1u == n;
-        const bool sil = (info[k] >> (8 + p)) & 1u;
-        const double t_loop = sil ? tf : tl, t_skip = sil ? tf : ts;  // TdpModel.cpp:19-29, keyed on the destination state
-        const double ep = e[k][p];
-        bad |= __ballot(valid && !(ep >= 0.0));
-        double v = kInfF;
-        uint32_t b = 0;
-        if (p >= 2) {  // skip, forward: in source order, a later one must be strictly better
-          const double s2 = (sc[k][p - 2] + t_skip) + ep, s1 = (sc[k][p - 1] + tf) + ep;
-          b = s1 < s2 ? bk[k][p - 1] : bk[k][p - 2];
-          v = dmin(s2, s1);
-        } else if (p == 1) {
-          v = (sc[k][0] + tf) + ep;
-          b = bk[k][0];
-        }
-        {  // loop, unless the source is the word end (word-end hypotheses are expanded across the boundary only, :130-158)
-          const double s0 = end ? kInfF : (sc[k][p] + t_loop) + ep;
-          b = s0 < v ? bk[k][p] : b;
-          v = dmin(v, s0);
-        }
-        if (p <= 1) {
-          // the collapsed word-boundary candidate (+inf while no word end is alive): after the in-word candidates, unless phase C
-          // finds a tie and an earlier word end.  Scored with position 0's emission (Recognizer.cpp:136,148-151)
-          const bool b_skip = p == 1 && !first_sil;
-          const double n_b = (base_we + (b_skip ? ts : tf)) + e[k][0];
-          if (we_in && valid && n_b == v) tie |= 1u << (2 * k + p);
-          b = n_b < v ? bkp_new : b;
-          v = dmin(v, n_b);
-          if (p == 0) {  // one-position word: its dead position-1 hypothesis still feeds best_score (:139,155)
-            const double dead = (base_we + (first_sil ? tf : ts)) + ep;
-            my_best = dmin(my_best, n == 1u ? dead : kInfF);
+      for (int p = 0; p < NPA; p++)
+        if (kind[k] == kGGeneral || (kind[k] == kGPlain && p < L) || p == 0) e[k][p] = *reinterpret_cast<const double*>(row_l + st[k][p]);
+    }
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+      if (kind[k] == kGPlain) {
+        // ---- plain: L positions, the last one the word end; penalties are the scalars tl, tf, ts, wp_word -------------------
+#pragma unroll
+        for (int p = L - 1; p >= 0; p--) {
+          const double ep = e[k][p];
+          bad |= __ballot(!(ep >= 0.0));
+          double v = kInfF;
+          uint32_t b = 0;
+          if (p >= 2) {  // skip, forward: in source order, a later one must be strictly better
+            const double s2 = (sc[k][p - 2] + ts) + ep, s1 = (sc[k][p - 1] + tf) + ep;
+            b = s1 < s2 ? bk[k][p - 1] : bk[k][p - 2];
+            v = dmin(s2, s1);
+          } else if (p == 1) {
+            v = (sc[k][0] + tf) + ep;
+            b = bk[k][0];
           }
+          if (p != L - 1) {  // loop, unless the source is the word end (word-end hypotheses are expanded across the boundary only, :130-158)
+            const double s0 = (sc[k][p] + tl) + ep;
+            b = s0 < v ? bk[k][p] : b;
+            v = dmin(v, s0);
+          }
+          if (p <= 1) {  // the boundary candidate, scored with position 0's emission (Recognizer.cpp:136,148-151)
+            const double n_b = (p == 1 ? cb_s : cb_f) + e[k][0];
+            tie[k][p] = __ballot(n_b == v) & real[k] & we_in;
+            b = n_b < v ? bkp_new : b;
+            v = dmin(v, n_b);
+          }
+          sc[k][p] = v; bk[k][p] = b;
+          my_best = dmin(my_best, v);
+          if (p == L - 1) my_we = dmin(my_we, v);
         }
-        v = valid ? v : kInfF;
-        nv[k][p] = v; nb[k][p] = b;
-        my_best = dmin(my_best, v);
-        my_we = dmin(my_we, end ? v : kInfF);
+      } else if (kind[k] == kGSingle) {
+        // ---- one-position words: the boundary candidate (position 0 is the word end: no loop) and the dead position-1
+        // hypothesis, which still feeds best_score (Recognizer.cpp:139,155) ------------------------------------------------------
+        uint32_t inf_k = info[k];
+        asm volatile("" : "+v"(inf_k));  // (nothing derived from the flags is to be hoisted out of the frame loop: registers)
+        const double ep = e[k][0];
+        bad |= __ballot(!(ep >= 0.0));
+        const double base_we = m_we + ((inf_k & kWSilWord) ? 0.0 : wp_word);
+        const double n_b = (base_we + tf) + ep;
+        const double dead = (base_we + ((inf_k & kWFirstSil) ? tf : ts)) + ep;
+        sc[k][0] = n_b; bk[k][0] = n_b < kInfF ? bkp_new : 0u;
+        my_best = dmin(my_best, dmin(n_b, dead));
+        my_we = dmin(my_we, n_b);
+      } else if (GEN && kind[k] == kGGeneral) {
+        // ---- general: 0 .. 4 positions per lane, silence word, silence states -------------------------------------------------
+        uint32_t inf_k = info[k];
+        asm volatile("" : "+v"(inf_k));
+        const uint32_t n = inf_k & 7u;
+        const bool sil_word = inf_k & kWSilWord, first_sil = inf_k & kWFirstSil;
+        const double base_we = m_we + (sil_word ? 0.0 : wp_word);
+#pragma unroll
+        for (int p = NPA - 1; p >= 0; p--) {
+          const bool valid = (uint32_t)p < n, end = (uint32_t)p + 1u == n;
+          const bool sil = (inf_k >> (8 + p)) & 1u;
+          const double t_loop = sil ? tf : tl, t_skip = sil ? tf : ts;  // TdpModel.cpp:19-29, keyed on the destination state
+          const double ep = e[k][p];
+          bad |= __ballot(valid && !(ep >= 0.0));
+          double v = kInfF;
+          uint32_t b = 0;
+          if (p >= 2) {
+            const double s2 = (sc[k][p - 2] + t_skip) + ep, s1 = (sc[k][p - 1] + tf) + ep;
+            b = s1 < s2 ? bk[k][p - 1] : bk[k][p - 2];
+            v = dmin(s2, s1);
+          } else if (p == 1) {
+            v = (sc[k][0] + tf) + ep;
+            b = bk[k][0];
+          }
+          {
+            const double s0 = end ? kInfF : (sc[k][p] + t_loop) + ep;
+            b = s0 < v ? bk[k][p] : b;
+            v = dmin(v, s0);
+          }
+          if (p <= 1) {
+            const bool b_skip = p == 1 && !first_sil;
+            const double n_b = (base_we + (b_skip ? ts : tf)) + e[k][0];
+            tie[k][p] = __ballot(valid && n_b == v) & we_in;
+            b = n_b < v ? bkp_new : b;
+            v = dmin(v, n_b);
+            if (p == 0) {
+              const double dead = (base_we + (first_sil ? tf : ts)) + ep;
+              my_best = dmin(my_best, n == 1u ? dead : kInfF);
+            }
+          }
+          v = valid ? v : kInfF;
+          sc[k][p] = v; bk[k][p] = b;
+          my_best = dmin(my_best, v);
+          my_we = dmin(my_we, end ? v : kInfF);
+        }
       }
     }
 
@@ -198,64 +271,73 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
     const double best = c_best[r], we = c_we[r];
     const double limit = best + thr;
     const bool we_alive = !(we > limit) && we != kInfF;
-    if (__ballot(tie != 0)) {  // rare: the boundary source came first where the first minimal word end of the class precedes the word
-      const uint32_t* ef_prev = e_first + 4 * r_prev;  // written in phase C of frame t - 1: complete since this frame's barrier
+    {
+      uint64_t tie_any = 0;
 #pragma unroll
-      for (int k = 0; k < NW; k++) {
-        const uint32_t n = info[k] & 7u, base = o_end[k] - (n - 1u);
-        const bool sil_word = info[k] & kWSilWord, first_sil = info[k] & kWFirstSil;
+      for (int k = 0; k < NW; k++) tie_any |= tie[k][0] | tie[k][1];
+      if (tie_any) {  // rare: the boundary source came first where the first minimal word end of the class precedes the word
+        const uint32_t* ef_prev = e_first + 4 * r_prev;  // written in phase C of frame t - 1: complete since this frame's barrier
 #pragma unroll
-        for (int p = 0; p < 2 && p < NP; p++) {
-          const bool b_skip = p == 1 && !first_sil;
-          const uint32_t cls = (sil_word ? 0u : 2u) + (b_skip ? 1u : 0u);
-          if ((tie >> (2 * k + p) & 1u) && ef_prev[cls] < base) nb[k][p] = bkp_new;  // the in-word candidate had to be strictly better
+        for (int k = 0; k < NW; k++) {
+          const uint32_t n = info[k] & 7u, base = o_end[k] - (n - 1u);
+          const bool sil_word = info[k] & kWSilWord, first_sil = info[k] & kWFirstSil;
+#pragma unroll
+          for (int p = 0; p < 2 && p < NPA; p++) {
+            const bool b_skip = p == 1 && !first_sil;
+            const uint32_t cls = (sil_word ? 0u : 2u) + (b_skip ? 1u : 0u);
+            if ((tie[k][p] >> lane & 1ull) && ef_prev[cls] < base) bk[k][p] = bkp_new;  // the in-word candidate had to be strictly better
+          }
         }
       }
     }
     if (t > 1) flush_pending(t - 1);
     m_we = we_alive ? we : kInfF;
     prev_alive = we_alive;
+    const double near = m_we + (fabs(m_we) + fabs(wp_word) + fabs(tf) + fabs(ts) + 1.0) * 1e-9;
+    double v_end[NW];
+    uint32_t b_end[NW];
+    uint64_t any_near = 0;
 #pragma unroll
-    for (int k = 0; k < NW; k++)
+    for (int k = 0; k < NW; k++) {
+      v_end[k] = kInfF; b_end[k] = 0;
+      if (kind[k] == kGSkip) continue;
 #pragma unroll
-      for (int p = 0; p < NP; p++) {
-        double v = nv[k][p];
+      for (int p = 0; p < NPA; p++) {
+        if ((kind[k] == kGPlain && p >= L) || (kind[k] == kGSingle && p >= 1)) continue;
+        double v = sc[k][p];
         if (v > limit) v = kInfF;  // :194-196
-        sc[k][p] = v; bk[k][p] = nb[k][p];
+        sc[k][p] = v;
       }
-    if (we_alive) {  // uniform
-      const double near = m_we + (fabs(m_we) + fabs(wp_word) + fabs(tf) + fabs(ts) + 1.0) * 1e-9;
-      double v_end[NW];
-      uint32_t b_end[NW];
-      uint64_t any_near = 0;
+      if (kind[k] == kGPlain) {
+        v_end[k] = sc[k][L - 1]; b_end[k] = bk[k][L - 1];
+      } else if (kind[k] == kGSingle) {
+        v_end[k] = sc[k][0]; b_end[k] = bk[k][0];
+      } else {
+        const uint32_t n = info[k] & 7u;
+#pragma unroll
+        for (int p = 0; p < NPA; p++)
+          if ((uint32_t)p + 1u == n) { v_end[k] = sc[k][p]; b_end[k] = bk[k][p]; }
+      }
+      any_near |= __ballot(v_end[k] <= near);
+    }
+    if (we_alive && any_near) {  // the wave that holds the minimum (about one lane of the block)
+      uint32_t* ef_nxt = e_first + 4 * r;
 #pragma unroll
       for (int k = 0; k < NW; k++) {
-        const uint32_t n = info[k] & 7u;
-        v_end[k] = kInfF; b_end[k] = 0;
-#pragma unroll
-        for (int p = 0; p < NP; p++)
-          if ((uint32_t)p + 1u == n) { v_end[k] = sc[k][p]; b_end[k] = bk[k][p]; }
-        any_near |= __ballot(v_end[k] <= near);
-      }
-      if (any_near) {  // the wave that holds the minimum (about one lane of the block)
-        uint32_t* ef_nxt = e_first + 4 * r;
-#pragma unroll
-        for (int k = 0; k < NW; k++) {
-          const double v = v_end[k];
-          if (v <= near) {
-            const uint32_t o = o_end[k];
-            if (v == m_we) {  // traceback[t] = the FIRST minimal surviving word end (:199-205): settled by the atomic, written after the next barrier
-              atomicMin(&c_widx[r], o);
-              // (a lane may hold several of them: it keeps the one with the smallest original index, the only one that can win)
-              if (!pend || o < pend_o) { pend_o = o; pend_w = tid + (uint32_t)k * nt; pend_b = b_end[k]; pend_v = v; }
-              pend = true;
-            }
-            // first word end per boundary class whose candidate (score + word penalty + tdp) equals the minimum's after rounding
-            if (v + 0.0 + tf == m_we + 0.0 + tf) atomicMin(&ef_nxt[0], o);
-            if (v + 0.0 + ts == m_we + 0.0 + ts) atomicMin(&ef_nxt[1], o);
-            if (v + wp_word + tf == m_we + wp_word + tf) atomicMin(&ef_nxt[2], o);
-            if (v + wp_word + ts == m_we + wp_word + ts) atomicMin(&ef_nxt[3], o);
+        const double v = v_end[k];
+        if (v <= near) {
+          const uint32_t o = o_end[k];
+          if (v == m_we) {  // traceback[t] = the FIRST minimal surviving word end (:199-205): settled by the atomic, written after the next barrier
+            atomicMin(&c_widx[r], o);
+            // (a lane may hold several of them: it keeps the one with the smallest original index, the only one that can win)
+            if (!pend || o < pend_o) { pend_o = o; pend_w = word[k]; pend_b = b_end[k]; pend_v = v; }
+            pend = true;
           }
+          // first word end per boundary class whose candidate (score + word penalty + tdp) equals the minimum's after rounding
+          if (v + 0.0 + tf == m_we + 0.0 + tf) atomicMin(&ef_nxt[0], o);
+          if (v + 0.0 + ts == m_we + 0.0 + ts) atomicMin(&ef_nxt[1], o);
+          if (v + wp_word + tf == m_we + wp_word + tf) atomicMin(&ef_nxt[2], o);
+          if (v + wp_word + ts == m_we + wp_word + ts) atomicMin(&ef_nxt[3], o);
         }
       }
     }
@@ -292,19 +374,17 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
   }
 }
 
-static size_t words_smem(uint32_t ld) { return kWordsCellBytes + 2 * (((size_t)ld * 8 + 1023u) & ~(size_t)1023u); }
+static size_t words_smem(uint32_t ld) { return kWordsCellBytes + 2 * (((size_t)ld * 8 + 16 + 1023u) & ~(size_t)1023u); }
 static constexpr size_t kLdsPerWorkgroup = 160 * 1024;
 
-bool decode_words_applies(const DecodeArgs& a) {
-  return a.words.info != nullptr && a.words.max_pos <= 4 && a.net.n_words <= 3 * 1024 && words_smem(a.ld) <= kLdsPerWorkgroup;
-}
+bool decode_words_applies(const DecodeArgs& a) { return a.words.info != nullptr && words_smem(a.ld) <= kLdsPerWorkgroup; }
+uint32_t decode_words_max_words() { return 3 * 1024; }
 
 hipError_t launch_decode_words(const DecodeArgs& a, hipStream_t stream) {
   if (a.n_utts == 0) return hipSuccess;
   if (!decode_words_applies(a)) return hipErrorInvalidValue;
-  const uint32_t W = a.net.n_words;
-  const uint32_t nw = (W + 1023) / 1024;                       // words per lane
-  const uint32_t nt = (((W + nw - 1) / nw) + 63) / 64 * 64;    // lanes, in whole waves
+  const uint32_t nw = a.words.nw, nt = a.words.nt;
+  if (nw < 1 || nw > 3 || nt == 0 || nt > 1024 || nt % 64) return hipErrorInvalidValue;
   const size_t smem = words_smem(a.ld);
   auto go = [&](auto kernel) {
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -312,14 +392,13 @@ hipError_t launch_decode_words(const DecodeArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL(kernel, dim3(a.n_utts), dim3(nt), smem, stream, a);
     return hipGetLastError();
   };
-  if (a.words.max_pos <= 3) {
-    if (nw == 1) return go(decode_words_kernel<1, 3>);
-    if (nw == 2) return go(decode_words_kernel<2, 3>);
-    return go(decode_words_kernel<3, 3>);
-  }
-  if (nw == 1) return go(decode_words_kernel<1, 4>);
-  if (nw == 2) return go(decode_words_kernel<2, 4>);
-  return go(decode_words_kernel<3, 4>);
+#define SR_WORDS_G(Lv, Gv) do { if (nw == 1) return go(decode_words_kernel<1, Lv, Gv>); if (nw == 2) return go(decode_words_kernel<2, Lv, Gv>); return go(decode_words_kernel<3, Lv, Gv>); } while (0)
+#define SR_WORDS(Lv) do { if (a.words.has_general) SR_WORDS_G(Lv, true); SR_WORDS_G(Lv, false); } while (0)
+  if (a.words.plain_len == 2) SR_WORDS(2);
+  if (a.words.plain_len == 4) SR_WORDS(4);
+  SR_WORDS(3);
+#undef SR_WORDS
+#undef SR_WORDS_G
 }
 
 }  // namespace srgpu
