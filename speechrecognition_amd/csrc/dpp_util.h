@@ -32,6 +32,11 @@ __device__ inline uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; 
 __device__ inline void atomic_min_f64_lds(double* cell, double v) {
   asm volatile("ds_min_f64 %0, %1" : : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)cell), "v"(v) : "memory");
 }
+// ... and the wait that has to stand between those atomics and the barrier: the compiler does not see the DS instruction inside
+// the asm, so its own "s_waitcnt lgkmcnt(0)" before s_barrier is there only when some OTHER LDS access happens to be pending --
+// without it a wave can pass the barrier while its minimum is still queued, and the waves that read the cell first see different
+// minima (round 3: one traceback entry in ~1e5 wrong, run to run, once a second copy of the frame loop was compiled without it).
+__device__ inline void lds_atomics_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 // full-wave minimum, returned to every lane
 __device__ inline double wave_min_dpp(double v) {
   v = dmin(v, dpp_d<0xB1, 0xF>(v));    // quad_perm [1,0,3,2]

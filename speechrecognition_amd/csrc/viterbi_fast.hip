@@ -342,6 +342,7 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
       my_we = row_min_dpp(my_we);
       if ((lane & 15u) == 0) atomic_min_f64_lds(&c_we[par], my_we);
     }
+    lds_atomics_done();
     __syncthreads();
 
     // ---- C: prune, publish the word-end minimum --------------------------------------------------------------------

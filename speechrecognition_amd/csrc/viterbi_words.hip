@@ -104,6 +104,8 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
   if (tid < 12) e_first[tid] = 0xFFFFFFFFu;
   if (tid < 3) { c_best[tid] = kInfF; c_we[tid] = kInfF; c_widx[tid] = 0xFFFFFFFFu; }
   if (tid == 12) *s_bad = 0;
+  // (Compiling the frame loop a second time for waves whose groups are all plain -- straight-line code, no dispatch on the group
+  // kind -- was measured too: 2.30 ms against 2.22, 126 registers and scratch against 119.)
   // (Fetching rows two frames ahead into three buffers was measured: 3.31 ms per step against 2.99 with the same geometry -- the
   // frame does not wait for its row; and the third buffer costs the second workgroup per CU, which is worth 2.99 -> 2.24 ms.)
   if (tid < 2) *reinterpret_cast<double*>(rows_lds + tid * row_pad + row_bytes) = kInfF;
@@ -264,6 +266,7 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
     my_best = row_min_dpp(my_best);
     my_we = row_min_dpp(my_we);
     if ((lane & 15u) == 0) { atomic_min_f64_lds(&c_best[r], my_best); atomic_min_f64_lds(&c_we[r], my_we); }
+    lds_atomics_done();
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of the next row have landed; the barrier publishes them
     __syncthreads();
 
