@@ -225,7 +225,7 @@ def main():
                 "shard_imbalance": max(shard_frames) / (sum(shard_frames) / world),  # heaviest shard / mean: what strong scaling can lose
             },
             "roofline": gmm_roofline(args, prof, n_frames, D, S),
-            "search": search_report(args, prof, S, int(word_off[-1]), padded_slots(word_off, automaton, lex.silence_idx, sil_state), n_frames, len(frame_off) - 1),
+            "search": search_report(args, prof, S, int(word_off[-1]), padded_slots(word_off, automaton, lex.silence_idx, sil_state), n_frames, len(frame_off) - 1, lexh.describe()),
             "recognised_words_rank0": int(woff[-1]),
         }
         if args.kernel == "prefilter":
@@ -322,19 +322,32 @@ def decode_geometry(P, n_utts):
     return None
 
 
-def search_report(args, prof, S, P, P_padded, n_frames, n_utts):
-    """The Viterbi step against SURVEY 8(d)'s HBM model (8*S + 4*P bytes per frame), next to what bounds it: the
-    frame-sequential recursion is a chain of ~380 instructions per wave and frame between two workgroup barriers, one
-    workgroup per CU (profiles/r3_decoder_diet.txt) -- HBM, which only delivers the score rows, is at a quarter of its peak."""
+def search_report(args, prof, S, P, P_padded, n_frames, n_utts, network):
+    """The Viterbi step against SURVEY 8(d)'s HBM model (8*S + 4*P bytes per frame).  `network` = sr_lexicon_describe: which
+    search kernel the library runs on this lexicon.  The word-per-lane kernel (short-word lexica: all of SURVEY 8d's) keeps the
+    hypotheses in registers and reads nothing but the score rows: its time is the rows' HBM fetch at one row in flight per
+    workgroup, two workgroups per CU; the slot-per-lane kernel is bound by its per-frame dependency chain."""
     ms = prof["search_ms"] / max(1, args.steps)
     algorithmic = prof["search_bytes"] / (prof["search_ms"] * 1e-3) / 1e9 if prof["search_ms"] > 0 else 0.0
-    traffic = pmc_traffic(args, n_frames, "decode_fast_kernel")
+    words = network.startswith("words")
+    traffic = pmc_traffic(args, n_frames, "decode_words_kernel" if words else "decode_fast_kernel")
     geom = decode_geometry(P_padded, n_utts)
+    if words:
+        _, nw, _, nt, _, L = network.split()[:6]
+        kernel = (f"decode_words_kernel<{nw}, {L}, {'true' if network.endswith('general') else 'false'}> x {nt} lanes (one lane per word, hypotheses in registers, "
+                  "score rows staged in LDS by LDS-DMA, one barrier per frame; + decode_kernel replay of flagged utterances)")
+        bound = "HBM fetch of the score rows (the only memory traffic) at one row in flight per workgroup, two workgroups per CU; then the per-frame barrier"
+    elif geom:
+        kernel = f"decode_fast_kernel<{geom}> (score rows staged in LDS by LDS-DMA when they fit; + decode_kernel replay of flagged utterances)"
+        bound = "latency of the per-frame dependency chain (two barriers per frame, one workgroup of 16 waves per CU); not HBM"
+    else:
+        kernel = "decode_big_kernel<1024> (hypotheses in device memory: more than 8192 type-padded slots)"
+        bound = "device-memory round trips of the hypothesis arrays"
     return {
-        "kernel": (f"decode_fast_kernel<{geom}> (score rows staged in LDS by LDS-DMA when they fit; + decode_kernel replay of flagged utterances)" if geom else
-                   "decode_big_kernel<1024> (hypotheses in device memory: more than 8192 type-padded slots)"),
+        "kernel": kernel,
+        "network": network,
         "ms_per_step": ms,
-        "bound": "latency of the per-frame dependency chain (two barriers per frame, one workgroup of 16 waves per CU); not HBM",
+        "bound": bound,
         "hbm_model": {"bytes_per_frame": 8.0 * S + 4.0 * P, "achieved_GBps": algorithmic, "peak_GBps": 8000.0, "frac": algorithmic / 8000.0},
         "hbm_measured_bytes_per_launch": traffic,
         "hbm_measured_GBps": traffic / (ms * 1e-3) / 1e9 if traffic and ms > 0 else None,

@@ -121,6 +121,10 @@ SR_API int sr_score_frames(sr_model* m, const float* feats, uint64_t n_frames, i
 SR_API int sr_lexicon_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, const uint16_t* automaton,
                       uint32_t silence_idx, const double tdp[3], uint16_t silence_state, sr_lexicon** out);
 SR_API int sr_lexicon_destroy(sr_lexicon* l);
+/* Which search kernel sr_recognize_corpus runs on this lexicon, as text (for logs and benchmark reports): "words <nw> x <lanes>
+ * plain <L> [general]" = the word-per-lane kernel (viterbi_words.hip), "slots" = the slot-per-lane kernel (viterbi_fast.hip),
+ * "big" = hypotheses in device memory.  out is NUL-terminated within cap bytes. */
+SR_API int sr_lexicon_describe(const sr_lexicon* l, char* out, size_t cap);
 
 typedef struct {
   double am_threshold; /* "am-threshold", Recognizer.cpp:31 (beam) */

@@ -25,7 +25,7 @@ SR_ECORRUPT = -7
 SYMBOLS = [
     "sr_last_error", "sr_device_count", "sr_model_create", "sr_model_load_mixset", "sr_model_destroy", "sr_model_info",
     "sr_corpus_upload", "sr_corpus_upload_async", "sr_corpus_wait", "sr_corpus_destroy", "sr_shard_utterances", "sr_recognize_batch_multi", "sr_score_corpus", "sr_score_frames", "sr_lexicon_create",
-    "sr_lexicon_destroy", "sr_recognize_corpus", "sr_traceback_corpus", "sr_traceback_words", "sr_recognize_batch", "sr_align_corpus", "sr_align_corpus_pruned", "sr_path_scores_corpus", "sr_model_create_from_statistics", "sr_model_create_from_accumulated", "sr_mixset_write", "sr_model_set_tying", "sr_model_tying_info", "sr_model_topology", "sr_accumulate_corpus",
+    "sr_lexicon_destroy", "sr_lexicon_describe", "sr_recognize_corpus", "sr_traceback_corpus", "sr_traceback_words", "sr_recognize_batch", "sr_align_corpus", "sr_align_corpus_pruned", "sr_path_scores_corpus", "sr_model_create_from_statistics", "sr_model_create_from_accumulated", "sr_mixset_write", "sr_model_set_tying", "sr_model_tying_info", "sr_model_topology", "sr_accumulate_corpus",
     "sr_bigram_create", "sr_bigram_destroy", "sr_recognize_bigram_corpus",
     "sr_probe_fp16_denormals", "sr_probe_fp16_accumulation",
     "sr_profile_enable", "sr_profile_reset", "sr_profile_read",
@@ -80,6 +80,7 @@ def lib():
         L.sr_score_frames.argtypes = [vp, vp, u64, i32, vp]
         L.sr_lexicon_create.argtypes = [vp, u32, vp, vp, u32, C.POINTER(dbl * 3), C.c_uint16, C.POINTER(vp)]
         L.sr_lexicon_destroy.argtypes = [vp]
+        L.sr_lexicon_describe.argtypes = [vp, C.c_char_p, C.c_size_t]
         L.sr_recognize_corpus.argtypes = [vp, vp, vp, C.POINTER(SearchParams), vp, vp, vp, vp, vp]
         L.sr_recognize_batch.argtypes = [vp, vp, C.POINTER(SearchParams), vp, vp, u32, vp, vp]
         L.sr_traceback_corpus.argtypes = [vp, vp, vp, vp, vp, vp, vp]
@@ -365,6 +366,12 @@ class Lexicon:
         t3 = (C.c_double * 3)(*tdp)
         _check(lib().sr_lexicon_create(model.h, len(word_off) - 1, _ptr(word_off), _ptr(automaton), silence_idx, C.byref(t3),
                                        silence_state, C.byref(self.h)))
+
+    def describe(self):
+        """Which search kernel sr_recognize_corpus runs on this lexicon (sr_lexicon_describe)."""
+        buf = C.create_string_buffer(128)
+        _check(lib().sr_lexicon_describe(self.h, buf, len(buf)))
+        return buf.value.decode()
 
     def close(self):
         if self.h:

@@ -948,6 +948,19 @@ int sr_lexicon_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, c
   });
 }
 
+int sr_lexicon_describe(const sr_lexicon* l, char* out, size_t cap) {
+  return guarded(__func__, [&]() -> int {
+  if (!l || !out || cap == 0) return fail(SR_EINVAL, "null argument");
+  DecodeArgs da{};
+  da.words.info = l->w_plain_len ? l->w_info.p : nullptr;
+  da.ld = l->model ? l->model->ld : 0;
+  if (l->big) snprintf(out, cap, "big (%u positions: hypotheses in device memory)", l->n_slots);
+  else if (decode_words_applies(da)) snprintf(out, cap, "words %u x %u plain %u%s", l->w_nw, l->w_nt, l->w_plain_len, l->w_general ? " general" : "");
+  else snprintf(out, cap, "slots (%u type-padded positions)", l->f_n);
+  return SR_OK;
+  });
+}
+
 int sr_lexicon_destroy(sr_lexicon* l) {
   return guarded(__func__, [&]() -> int {
   if (!l) return SR_OK;
