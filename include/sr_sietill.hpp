@@ -616,7 +616,7 @@ class LinearSearch {
     std::vector<uint64_t> off(n + 1);
     sr_corpus* c = nullptr;
     check(sr_corpus_upload(scorer_.handle(), corpus.features(), corpus.frame_offsets(), (uint32_t)n, &c));
-    const sr_bigram_params p = {acoustic_pruning_, lm_pruning_, scorer_.gmm_kernel, 0};
+    const sr_bigram_params p = {acoustic_pruning_, lm_pruning_, scorer_.gmm_kernel, /*max_word_ends*/ 0, /*flags*/ 0};
     const int rc = sr_recognize_bigram_corpus(scorer_.handle(), c, net_, &p, words.data(), scores.data(), times.data(), off.data());
     sr_corpus_destroy(c);
     check(rc);

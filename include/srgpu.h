@@ -235,7 +235,12 @@ typedef struct {
   float lm_pruning;         /* "lm-pruning" (:444-445) */
   int gmm_kernel;
   uint32_t max_word_ends;   /* traceback book capacity per frame and utterance; 0 = W (cannot overflow) */
+  int flags;                /* 0, or SR_BIGRAM_DENSE_STATES */
 } sr_bigram_params;
+/* Lexica whose words all have at most four states (and at most 3072 words) keep the state hypotheses of a word in the registers
+ * of one lane (viterbi_bigram.hip, KS > 0); this flag keeps them in the dense LDS image every other lexicon uses.  Same results;
+ * for cross-checking the two. */
+#define SR_BIGRAM_DENSE_STATES 1
 SR_API int sr_bigram_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, const uint16_t* mixtures,
                             uint32_t silence_word, const float* lm, const float tdp[8], sr_bigram** out);
 SR_API int sr_bigram_destroy(sr_bigram* b);

@@ -348,7 +348,11 @@ size_t orc_decode_pruned(const orc_model* m, const double* dense, size_t dense_s
     n_pos[w] = lex->word_off[w + 1] - lex->word_off[w];
     if (n_pos[w] > max_pos) max_pos = n_pos[w];
   }
-  const size_t n_slots = S * max_pos; /* Recognizer.cpp:116-117 (over-allocated like the reference) */
+  /* Recognizer.cpp:116-117 allocates n_states * max_pos hypotheses and indexes them by word * max_pos + pos: enough because
+   * Lexicon::add_word gives every word fresh states (n_states >= n_words).  A lexicon whose words SHARE states can have fewer
+   * states than words; the reference would index past its arrays there (undefined).  The restatement allocates for the words
+   * it has -- the defined extension, and what the GPU kernels compute. */
+  const size_t n_slots = (S > W ? S : W) * max_pos;
   const hyp_t dead = {INFINITY, 0, 0, 0};
   hyp_t* cur = (hyp_t*)malloc(sizeof(hyp_t) * n_slots);
   hyp_t* nxt = (hyp_t*)malloc(sizeof(hyp_t) * n_slots);

@@ -19,6 +19,7 @@ GMM_MFMA, GMM_EXACT, GMM_PREFILTER = 0, 1, 2
 POOL_GLOBAL, POOL_MIXTURE, POOL_NONE = 0, 1, 2
 SEARCH_GENERAL_KERNEL = 1
 SEARCH_SLOT_KERNEL = 2
+BIGRAM_DENSE_STATES = 1
 SR_ECORRUPT = -7
 
 # every symbol include/srgpu.h declares
@@ -43,7 +44,7 @@ class SearchParams(C.Structure):
 
 
 class BigramParams(C.Structure):
-    _fields_ = [("acoustic_pruning", C.c_float), ("lm_pruning", C.c_float), ("gmm_kernel", C.c_int), ("max_word_ends", C.c_uint32)]
+    _fields_ = [("acoustic_pruning", C.c_float), ("lm_pruning", C.c_float), ("gmm_kernel", C.c_int), ("max_word_ends", C.c_uint32), ("flags", C.c_int)]
 
 
 class Profile(C.Structure):
@@ -338,12 +339,12 @@ class Corpus:
                                           _ptr(va), _ptr(vw)))
         return ma, mw, va, vw
 
-    def recognize_bigram(self, bigram, acoustic_pruning=FLT_MAX, lm_pruning=FLT_MAX, kernel=GMM_PREFILTER, max_word_ends=0):
+    def recognize_bigram(self, bigram, acoustic_pruning=FLT_MAX, lm_pruning=FLT_MAX, kernel=GMM_PREFILTER, max_word_ends=0, dense_states=False):
         """-> (words u32[], scores f32[], times u32[], off u64[n_utts+1]): LinearSearch::getResult per utterance"""
         cap = max(self.n_frames + self.n_utts, 1)
         ow, osc, ot = np.zeros(cap, np.uint32), np.zeros(cap, np.float32), np.zeros(cap, np.uint32)
         off = np.zeros(self.n_utts + 1, np.uint64)
-        p = BigramParams(acoustic_pruning, lm_pruning, kernel, max_word_ends)
+        p = BigramParams(acoustic_pruning, lm_pruning, kernel, max_word_ends, BIGRAM_DENSE_STATES if dense_states else 0)
         _check(lib().sr_recognize_bigram_corpus(self.model.h, self.h, bigram.h, C.byref(p), _ptr(ow), _ptr(osc), _ptr(ot), _ptr(off)))
         n = int(off[-1])
         return ow[:n], osc[:n], ot[:n], off

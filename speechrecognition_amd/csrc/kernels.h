@@ -210,9 +210,13 @@ struct BigramArgs {
   const uint64_t* book_off;     // [n_utts_total+1]
   uint32_t* out_word; float* out_score; uint32_t* out_time;  // [frames + utts]: utterance u at frame_off[u] + u
   uint32_t *out_count, *out_flags;  // [n_utts_total]; flag 1 = book capacity exceeded
+  uint32_t max_slot_states;     // most states of any slot
+  uint32_t silence_states;      // states of the silence word (= of every silence copy)
+  uint32_t dense_states;        // keep the state hypotheses in the dense LDS image even where the register layout applies
 };
 hipError_t launch_bigram(const BigramArgs& a, hipStream_t stream);
 size_t bigram_lds_bytes(uint32_t n_words, uint32_t n_positions);
+bool bigram_register_layout(const BigramArgs& a);   // short words, <= 3072 of them, the emission row fits the LDS beside the lists
 uint32_t bigram_max_words();
 
 // out[f] = scores[(f - frame_base) * ld + states[f]] for f in [f0, f1)  (Trainer::calc_am_score, Training.cpp:605)

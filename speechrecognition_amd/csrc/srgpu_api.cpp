@@ -1158,6 +1158,8 @@ int sr_bigram_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, co
   sr_bigram* b = new sr_bigram();
   std::unique_ptr<sr_bigram, int (*)(sr_bigram*)> own(b, sr_bigram_destroy);
   b->model = m; b->n_words = W; b->silence = silence_word; b->n_positions = P2;
+  for (uint32_t a2 = 0; a2 < 2 * W; a2++) b->max_slot_states = std::max(b->max_slot_states, slot_off[a2 + 1] - slot_off[a2]);
+  b->silence_states = n_sil;
   memcpy(b->tdp, tdp, sizeof(b->tdp));
   hipError_t e;
   if ((e = b->slot_off.upload(slot_off.data(), slot_off.size())) != hipSuccess ||
@@ -1219,6 +1221,8 @@ int sr_recognize_bigram_corpus(sr_model* m, sr_corpus* c, sr_bigram* b, const sr
   ba.slot_off = b->slot_off.p; ba.slot_mix = b->slot_mix.p; ba.mixtures = b->mixtures.p; ba.pos_info = b->pos_info.p; ba.pos_slot = b->pos_slot.p; ba.lmT = b->lmT.p; ba.lm_rowmin = b->lm_rowmin.p; ba.lm_rowmax = b->lm_rowmax.p;
   memcpy(ba.tdp, b->tdp, sizeof(ba.tdp));
   ba.ac_pruning = p->acoustic_pruning; ba.lm_pruning = p->lm_pruning;
+  if (p->flags & ~SR_BIGRAM_DENSE_STATES) return fail(SR_EINVAL, "unknown sr_bigram_params.flags 0x%x", (unsigned)p->flags);
+  ba.max_slot_states = b->max_slot_states; ba.silence_states = b->silence_states; ba.dense_states = (p->flags & SR_BIGRAM_DENSE_STATES) ? 1u : 0u;
   ba.we_slot = b->we_slot.p; ba.we_bp = b->we_bp.p; ba.we_score = b->we_score.p;
   ba.book = b->book.p; ba.book_off = b->book_off.p;
   ba.out_word = b->out_word.p; ba.out_score = b->out_score.p; ba.out_time = b->out_time.p;

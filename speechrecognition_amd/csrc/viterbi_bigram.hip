@@ -38,6 +38,16 @@ static constexpr float kFltMax = 3.402823466e+38f;
 // flags on a word end of the merged list (see step 6): the same word end also sits LATER in the list / sat EARLIER
 static constexpr uint32_t kShadowed = 0x80000000u, kRepeat = 0x40000000u, kSlotMask = 0x3FFFFFFFu;
 
+// LDS image without the state hypotheses: entries, staging, scan scratch, the two active lists, the flags
+__host__ __device__ constexpr size_t bigram_lds_small(uint32_t n_words) {
+  return 2 * (size_t)n_words * 8 + (3 * kBgStage + kBgWaves + 1 + kBgWaves) * 4 + 2 * (size_t)n_words * 2 * 2 + 2 * (size_t)n_words + 64;
+}
+
+// register layout: offset of the emission row behind the small image and the LM row bounds
+__host__ __device__ constexpr size_t bigram_lds_row_off(uint32_t n_words) {
+  return (((bigram_lds_small(n_words) + 15u) & ~(size_t)15u) + 2 * (size_t)n_words * 4 + 1023u) & ~(size_t)1023u;
+}
+
 // inclusive prefix sum over the wave with DPP row shifts and broadcasts (six vector instructions; __shfl_up is a
 // ds_bpermute round trip per step)
 __device__ inline uint32_t wave_incl_scan(uint32_t v, int /*lane*/) {
@@ -78,11 +88,21 @@ __device__ inline float wg_min(float v, float* tmp) {
   return r;
 }
 
-template <int KW, int KP>  // words per thread in the recombination: W <= KW * kBgThreads; positions per thread in the state update
+// Two layouts of the state hypotheses (steps 3 and 4):
+//   KS == 0  dense in LDS, one thread per POSITION (KP positions per thread): any lexicon whose image fits the LDS;
+//   KS >  0  in REGISTERS, one lane per SLOT: lane tid owns the words tid + k * 1024 (k < KS = KW, at most NP states each) and their
+//            silence copies (one state: the layout asks for a one-state silence) -- lexica of short words (every BASELINE
+//            configuration).  A slot's transitions stay inside the slot, so the expansion is arithmetic on
+//            the lane's own registers in descending state order: no LDS image of the states (85 KB at configs[4]), no "all old
+//            states read" barrier, no atomics for the survivor flags; the frame's emission costs are staged in LDS by LDS-DMA
+//            (one row buffer, fetched while steps 4-6 and 1-2 of the next frame run).  The final state of a surviving word end is
+//            published through the entry arrays, which are dead between step 3 and step 5.
+template <int KW, int KP, int KS, int NP>  // KW words per thread in the recombination: W <= KW * kBgThreads
 __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
+  constexpr bool REGS = KS > 0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t W = a.n_words, W2 = 2 * a.n_words, P2 = a.n_positions, sil = a.silence;
-  float* st_score = reinterpret_cast<float*>(smem);           // [P2]
+  const uint32_t W = a.n_words, W2 = 2 * a.n_words, P2 = REGS ? 0u : a.n_positions, sil = a.silence;
+  float* st_score = reinterpret_cast<float*>(smem);           // [P2]   (dense layout only)
   uint32_t* st_bp = reinterpret_cast<uint32_t*>(st_score + P2);  // [P2]
   float* en_score = reinterpret_cast<float*>(st_bp + P2);     // [2W] entry (start) hypotheses; scratch in step 5
   uint32_t* en_bp = reinterpret_cast<uint32_t*>(en_score + W2);  // [2W]
@@ -93,6 +113,15 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
   L[0] = reinterpret_cast<uint16_t*>(red_tmp + kBgWaves);     // [2W] active word slots, activation order
   L[1] = L[0] + W2;
   uint8_t* active = reinterpret_cast<uint8_t*>(L[1] + W2);    // [2W]
+  // register layout: the LM row bounds of the skip test (2 x W floats: from global memory they are a dependent round trip in
+  // three passes of step 1), then the frame's emission costs (ld doubles), 1 KB aligned
+  float* lm_lo_lds = reinterpret_cast<float*>(smem + ((bigram_lds_small(a.n_words) + 15u) & ~(size_t)15u));
+  float* lm_hi_lds = lm_lo_lds + W;
+  unsigned char* row_lds = smem + bigram_lds_row_off(a.n_words);
+  auto rowmin = [&](uint32_t h) -> float { if constexpr (REGS) return lm_lo_lds[h]; else return a.lm_rowmin[h]; };
+  auto rowmax = [&](uint32_t h) -> float { if constexpr (REGS) return lm_hi_lds[h]; else return a.lm_rowmax[h]; };
+  float* fin_score = en_score;                                // [2W] final-state score / back pointer of the slots whose word end survived
+  uint32_t* fin_bp = en_bp;                                   //      (written in step 4, read by its compaction; the entries are consumed by then)
 
   const uint32_t u = a.utt_order ? a.utt_order[a.utt_first + blockIdx.x] : a.utt_first + blockIdx.x, tid = threadIdx.x;
   const uint64_t f0 = a.frame_off[u], T = a.frame_off[u + 1] - f0;
@@ -114,6 +143,46 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
 
   for (uint32_t i = tid; i < P2; i += kBgThreads) { st_score[i] = __builtin_inff(); st_bp[i] = 0; }
   for (uint32_t i = tid; i < W2; i += kBgThreads) active[i] = 0;
+  // register layout: word w = tid + k * 1024 (slot w) and its silence copy (slot W + w): state count, silence flag, row offsets of the
+  // states, hypotheses
+  constexpr int KSR = REGS ? KS : 1, NPR = REGS ? NP : 1;
+  uint32_t r_n[KSR], r_st[KSR][(NPR + 1) / 2], r_bp[KSR][NPR], rc_bp[KSR];  // r_st: two 16-bit state ids per register
+  float r_sc[KSR][NPR], rc_sc[KSR];
+  bool r_sil[KSR];
+  const uint32_t wave = tid >> 6, lane = tid & 63;
+  const uint32_t row_bytes = a.ld * 8u;
+  const uint32_t sil_st = REGS ? (a.pos_info[a.slot_off[sil]] & 0xFFFFu) * 8u : 0u;  // row offset of the silence state (every copy's state)
+  auto issue_row = [&](uint64_t frame /* 1-based */) {  // every wave copies its share of the row's 1 KB pieces (LDS-DMA: no registers)
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(dense + (frame - 1) * a.ld);
+    for (uint32_t piece = wave; piece * 1024u < row_bytes; piece += kBgWaves) {
+      const uint32_t off = piece * 1024u + lane * 16u;
+      if (off < row_bytes)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
+                                         (__attribute__((address_space(3))) void*)(row_lds + piece * 1024u), 16, 0, 0);
+    }
+  };
+  if (REGS) {
+    for (uint32_t i = tid; i < W; i += kBgThreads) { lm_lo_lds[i] = a.lm_rowmin[i]; lm_hi_lds[i] = a.lm_rowmax[i]; }
+#pragma unroll
+    for (int k = 0; k < KSR; k++) {
+      const uint32_t w = tid + (uint32_t)k * kBgThreads;
+      const bool in = w < W;
+      const uint32_t j0 = in ? a.slot_off[w] : 0u;
+      r_n[k] = in ? a.slot_off[w + 1] - j0 : 0u;
+      r_sil[k] = in && w == sil;
+#pragma unroll
+      for (int p = 0; p < (NPR + 1) / 2; p++) r_st[k][p] = 0;
+#pragma unroll
+      for (int p = 0; p < NPR; p++) {
+        if ((uint32_t)p < r_n[k]) r_st[k][p / 2] |= (a.pos_info[j0 + p] & 0xFFFFu) << (16 * (p & 1));
+        r_sc[k][p] = __builtin_inff();
+        r_bp[k][p] = 0;
+      }
+      rc_sc[k] = __builtin_inff();
+      rc_bp[k] = 0;
+    }
+    if (T > 0) issue_row(1);
+  }
   // initialize (:211-216, :397-418 at t = 0): book[0] = sentinel, book[1] = (silence, 0, self, 0); one word end
   uint32_t n_book = 2, n_we = 1, n_L = 0;
   int cur = 0, lcur = 0;  // we_*[cur] = current word ends, L[lcur] = current active list
@@ -140,7 +209,7 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
     // for the rounded sums).  With a beam of 200 over LM scores spanning ~10 this drops most of the E x W work.
     float lu = kFltMax;
     for (uint32_t e = tid; e < n_we; e += kBgThreads)
-      lu = fminf(lu, we_score[cur][e] + a.lm_rowmax[map_copy(we_slot[cur][e] & kSlotMask)]);
+      lu = fminf(lu, we_score[cur][e] + rowmax(map_copy(we_slot[cur][e] & kSlotMask)));
     const float U = wg_min(lu, red_tmp);
     // staging buffer: the dedicated 256 entries, or -- for a big lexicon -- the idle half of the active-list double
     // buffer (it is rewritten from scratch in step 4), up to one entry per thread: fewer passes and barriers
@@ -166,7 +235,7 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
         en_score[c] = sc_e;
         en_bp[c] = we_bp[cur][e];
       }
-      n_keep += !(sc_e + a.lm_rowmin[map_copy(sl)] > U) ? 1u : 0u;
+      n_keep += !(sc_e + rowmin(map_copy(sl)) > U) ? 1u : 0u;
     }
     uint32_t ne_all;
     const uint32_t keep_pos = wg_excl_scan(n_keep, scan_tmp, &ne_all);
@@ -176,7 +245,7 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
       for (uint32_t e = e1_lo; e < e1_hi; e++) {
         const uint32_t sl = we_slot[cur][e] & kSlotMask, h = map_copy(sl);
         const float sc_e = we_score[cur][e];
-        if (!(sc_e + a.lm_rowmin[h] > U)) {
+        if (!(sc_e + rowmin(h) > U)) {
           if (pos >= r0 && pos - r0 < stg_cap) {
             stg[3 * (pos - r0)] = h;
             stg[3 * (pos - r0) + 1] = __float_as_uint(sc_e);
@@ -187,12 +256,13 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
       }
       __syncthreads();
       const uint32_t ne = (ne_all - r0 < stg_cap) ? ne_all - r0 : stg_cap;
-      // eight word ends at a time: their LM rows are loaded first (independent loads in flight together), then
-      // compared in list order
-      for (uint32_t e = 0; e < ne; e += 8) {
-        float v[8][KW];
+      // eight word ends at a time (two in the register layout, whose state hypotheses stay live across this loop): their LM rows
+      // are loaded first (independent loads in flight together), then compared in list order
+      constexpr int KE = REGS ? 2 : 8;
+      for (uint32_t e = 0; e < ne; e += KE) {
+        float v[KE][KW];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < KE; j++) {
           const uint32_t ej = (e + j < ne) ? e + j : e;
           const float* row = a.lmT + (uint64_t)stg[3 * ej] * W;
 #pragma unroll
@@ -202,7 +272,7 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
           }
         }
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < KE; j++) {
           if (e + j < ne) {  // workgroup-uniform
             const float sc = __uint_as_float(stg[3 * (e + j) + 1]);
             const uint32_t bp = stg[3 * (e + j) + 2];
@@ -274,6 +344,7 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
         }
       }
       n_L += total >> 16;
+      if (REGS) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of the frame's row have landed; the barrier publishes them
       __syncthreads();
     }
 
@@ -285,14 +356,66 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
     // A slot that is not active holds +inf everywhere and has no entry hypothesis, so updating it is a no-op; the new state s
     // needs the OLD states s-2, s-1, s: all reads, a barrier, then the writes.  Candidates in the order the reference creates
     // them (ascending predecessor state, entry first); >= lets the later one win.
+    float lbest = kFltMax;
+    constexpr int KPD = REGS ? 1 : KP;
+    float nsc[KPD];
+    uint32_t nbp[KPD];
+    if constexpr (REGS) {
+      // ---- register layout: the lane's words, states descending in place (new state s needs the old s, s - 1, s - 2), then their
+      // silence copies (one state: entry or loop) ------------------------------------------------------------------------------
+      const float inf = __builtin_inff();
+      const float pem_sil = (float)*reinterpret_cast<const double*>(row_lds + sil_st);
+#pragma unroll
+      for (int k = 0; k < KS; k++) {
+        const uint32_t w = tid + (uint32_t)k * kBgThreads;
+        const bool sil_ = r_sil[k];
+        const float t0 = sil_ ? a.tdp[1][0] : a.tdp[0][0], t1 = sil_ ? a.tdp[1][1] : a.tdp[0][1], t2 = sil_ ? a.tdp[1][2] : a.tdp[0][2];
+        const float ent = w < W ? en_score[w] : inf;
+        const uint32_t ebp = w < W ? en_bp[w] : 0u;
+        float pem[NP];
+#pragma unroll
+        for (int p = 0; p < NP; p++) pem[p] = (float)*reinterpret_cast<const double*>(row_lds + ((r_st[k][p / 2] >> (16 * (p & 1))) & 0xFFFFu) * 8u);
+#pragma unroll
+        for (int p = NP - 1; p >= 0; p--) {
+          const bool in = (uint32_t)p < r_n[k];
+          float best = inf;
+          uint32_t bb = 0;
+          // candidates in ascending predecessor order, >= lets the later one win: the virtual entry state 0 (free into state 1,
+          // skip penalty into state 2), then s - 2, s - 1, s
+          if (p == 0) { if (ent < inf) { best = ent; bb = ebp; } }
+          if (p == 1) { if (ent < inf) { best = ent + t2; bb = ebp; } }
+          if (p >= 2) { const float o = r_sc[k][p - 2], c = o + t2; if (o < inf && !(best < c)) { best = c; bb = r_bp[k][p - 2]; } }
+          if (p >= 1) { const float o = r_sc[k][p - 1], c = o + t1; if (o < inf && !(best < c)) { best = c; bb = r_bp[k][p - 1]; } }
+          { const float o = r_sc[k][p], c = o + t0; if (o < inf && !(best < c)) { best = c; bb = r_bp[k][p]; } }
+          if (!in) best = inf;
+          if (best < inf) {
+            best += pem[p];
+            lbest = fminf(lbest, best);
+          }
+          r_sc[k][p] = best;
+          r_bp[k][p] = best < inf ? bb : 0u;
+        }
+        // the copy: slot W + w (the silence word itself has none)
+        const bool has_copy = w < W && w != sil;
+        const float cent = has_copy ? en_score[W + w] : inf;
+        const uint32_t cebp = has_copy ? en_bp[W + w] : 0u;
+        float best = inf;
+        uint32_t bb = 0;
+        if (cent < inf) { best = cent; bb = cebp; }
+        { const float o = rc_sc[k], c = o + a.tdp[1][0]; if (o < inf && !(best < c)) { best = c; bb = rc_bp[k]; } }
+        if (best < inf) {
+          best += pem_sil;
+          lbest = fminf(lbest, best);
+        }
+        rc_sc[k] = best;
+        rc_bp[k] = best < inf ? bb : 0u;
+      }
+    } else {
     const double* row = dense + (t - 1) * a.ld;
     // kCh positions at a time: emission state | flags, slot (frame-invariant, but held in registers across the frame loop they
     // spill: coalesced reloads are cheaper) and emission cost, loads in flight together, then the four updates.
     constexpr int kCh = 4;
     static_assert(KP % kCh == 0, "positions per thread come in chunks of four");
-    float nsc[KP];
-    uint32_t nbp[KP];
-    float lbest = kFltMax;
 #pragma unroll
     for (int k0 = 0; k0 < KP; k0 += kCh) {
     __builtin_amdgcn_sched_barrier(0);  // (chunks interleaved by the scheduler need more registers than there are)
@@ -370,12 +493,46 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
       if (j < P2) { st_score[j] = nsc[k]; st_bp[j] = nbp[k]; }
     }
     for (uint32_t i = tid; i < W2; i += kBgThreads) active[i] &= 1u;  // bit 0 = on the active list; bits 1, 2 = this frame's survivors
+    }
     const float best_score = wg_min(lbest, red_tmp);
     float ac_thr = a.ac_pruning;
     if (ac_thr < kFltMax) ac_thr += best_score;
+    if (REGS && t < T) issue_row(t + 1);  // every wave is past its reads of this frame's row (the barrier inside wg_min)
 
     // ---- 4 pruneStatesAndFindWordEnds: the acoustic beam per position, then the ordered compaction of the active list ---
-    {
+    if constexpr (REGS) {
+#pragma unroll
+      for (int k = 0; k < KS; k++) {
+        const uint32_t w = tid + (uint32_t)k * kBgThreads;
+        const float pen = r_sil[k] ? a.tdp[1][3] : a.tdp[0][3];
+        uint32_t flags = 0;
+        float f_sc = 0.0f;
+        uint32_t f_bp = 0;
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+          const float v = r_sc[k][p];
+          if (v < __builtin_inff()) {
+            if (v + pen < ac_thr) {
+              flags |= 2u;
+              if ((uint32_t)p + 1u == r_n[k]) { flags |= 4u; f_sc = v; f_bp = r_bp[k][p]; }  // its final state too
+            } else {
+              r_sc[k][p] = __builtin_inff();
+            }
+          }
+        }
+        if (w < W) {  // bit 0 = on the active list; bits 1, 2 = this frame's survivors
+          active[w] = (uint8_t)((active[w] & 1u) | flags);
+          if (flags & 4u) { fin_score[w] = f_sc; fin_bp[w] = f_bp; }
+          uint32_t cflags = 0;
+          if (rc_sc[k] < __builtin_inff()) {
+            if (rc_sc[k] + a.tdp[1][3] < ac_thr) cflags = 6u;  // (one state: alive = its final state alive)
+            else rc_sc[k] = __builtin_inff();
+          }
+          active[W + w] = (uint8_t)((active[W + w] & 1u) | cflags);
+          if (cflags) { fin_score[W + w] = rc_sc[k]; fin_bp[W + w] = rc_bp[k]; }
+        }
+      }
+    } else {
       uint32_t* active_w = reinterpret_cast<uint32_t*>(active);  // (byte flags, OR-ed through their 32-bit word)
 #pragma unroll
       for (int k = 0; k < KP; k++) {
@@ -411,10 +568,15 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
       active[sl] = 1;
       L[lcur ^ 1][pa++] = (uint16_t)sl;
       if (fa & 4u) {  // the final state survived: a word end, carrying the exit-penalised score
-        const uint32_t last = a.slot_off[sl + 1] - 1;
         we_slot[nxt][pe] = sl;
-        we_score[nxt][pe] = st_score[last] + exit_pen[is_sil(sl)];
-        we_bp[nxt][pe] = st_bp[last];
+        if (REGS) {
+          we_score[nxt][pe] = fin_score[sl] + exit_pen[is_sil(sl)];
+          we_bp[nxt][pe] = fin_bp[sl];
+        } else {
+          const uint32_t last = a.slot_off[sl + 1] - 1;
+          we_score[nxt][pe] = st_score[last] + exit_pen[is_sil(sl)];
+          we_bp[nxt][pe] = st_bp[last];
+        }
         pe++;
       }
     }
@@ -499,15 +661,18 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
   }
 }
 
-size_t bigram_lds_bytes(uint32_t n_words, uint32_t n_positions) {
-  const size_t W2 = 2 * (size_t)n_words;
-  return (size_t)n_positions * 8 + W2 * 8 + (3 * kBgStage + kBgWaves + 1 + kBgWaves) * 4 + W2 * 2 * 2 + W2 + 64;
-}
+size_t bigram_lds_bytes(uint32_t n_words, uint32_t n_positions) { return (size_t)n_positions * 8 + bigram_lds_small(n_words); }
 uint32_t bigram_max_words() { return 8 * kBgThreads; }
+
+static size_t bigram_lds_regs(uint32_t n_words, uint32_t ld) { return bigram_lds_row_off(n_words) + (((size_t)ld * 8 + 1023u) & ~(size_t)1023u); }
+bool bigram_register_layout(const BigramArgs& a) {
+  return !a.dense_states && a.max_slot_states <= 4 && a.silence_states == 1 && a.n_words <= 3 * kBgThreads && bigram_lds_regs(a.n_words, a.ld) <= 160 * 1024;
+}
 
 hipError_t launch_bigram(const BigramArgs& a, hipStream_t stream) {
   if (a.n_utts == 0) return hipSuccess;
-  const size_t smem = (bigram_lds_bytes(a.n_words, a.n_positions) + 15) & ~(size_t)15;
+  const bool regs = bigram_register_layout(a);
+  const size_t smem = regs ? bigram_lds_regs(a.n_words, a.ld) : (bigram_lds_bytes(a.n_words, a.n_positions) + 15) & ~(size_t)15;
   auto go = [&](auto kernel) {
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
@@ -515,7 +680,14 @@ hipError_t launch_bigram(const BigramArgs& a, hipStream_t stream) {
     return hipGetLastError();
   };
   const uint32_t kw = (a.n_words + kBgThreads - 1) / kBgThreads, kp = (a.n_positions + kBgThreads - 1) / kBgThreads;
-#define SR_BG(KWv, KPv) return go(bigram_kernel<KWv, KPv>)
+  if (regs) {  // lane tid: words tid + k * 1024 and their silence copies; three or four states per word
+#define SR_BG_R(KWv) do { if (a.max_slot_states <= 3) return go(bigram_kernel<KWv, 4, KWv, 3>); return go(bigram_kernel<KWv, 4, KWv, 4>); } while (0)
+    if (kw <= 1) SR_BG_R(1);
+    if (kw <= 2) SR_BG_R(2);
+    SR_BG_R(3);
+#undef SR_BG_R
+  }
+#define SR_BG(KWv, KPv) return go(bigram_kernel<KWv, KPv, 0, 0>)
 #define SR_BG_KP(KWv) do { if (kp <= 4) SR_BG(KWv, 4); if (kp <= 12) SR_BG(KWv, 12); if (kp <= 20) SR_BG(KWv, 20); return hipErrorInvalidValue; } while (0)
   if (kw <= 1) SR_BG_KP(1);
   if (kw <= 2) SR_BG_KP(2);

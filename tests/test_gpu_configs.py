@@ -104,6 +104,9 @@ def test_cfg5_bigram_at_size_vs_restatement(tmp_path, oracle_lib):
         # ---- 100 utterances: permutation invariance --------------------------------------------------------------
         c1 = m.upload(feats100, off100)
         w1, s1, t1, o1 = c1.recognize_bigram(bg, 200.0, capi.FLT_MAX)
+        # (three-state words, one four-state word: the state hypotheses live in registers; the dense LDS layout must agree)
+        wd, sd, td, od = c1.recognize_bigram(bg, 200.0, capi.FLT_MAX, dense_states=True)
+        assert np.array_equal(w1, wd) and np.array_equal(t1, td) and np.array_equal(o1, od) and np.array_equal(s1.view(np.uint32), sd.view(np.uint32))
         c1.close()
         perm = np.random.default_rng(35).permutation(100)
         lens = np.diff(off100.astype(np.int64))

@@ -20,8 +20,8 @@ def driver():
     from speechrecognition_amd import build
     build.build()
     src = os.path.join(ROOT, "tests", "cpp", "host_mirror_driver.cpp")
-    hdr = os.path.join(ROOT, "include", "sr_sietill.hpp")
-    if not os.path.exists(DRIVER) or os.path.getmtime(DRIVER) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    hdrs = [os.path.join(ROOT, "include", "sr_sietill.hpp"), os.path.join(ROOT, "include", "srgpu.h")]  # (struct layouts live in srgpu.h)
+    if not os.path.exists(DRIVER) or os.path.getmtime(DRIVER) < max(os.path.getmtime(f) for f in [src] + hdrs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(ROOT, "include"), src, "-o", DRIVER,
                                "-L" + os.path.join(ROOT, "speechrecognition_amd"), "-lsrgpu",
                                "-Wl,-rpath,$ORIGIN/../../speechrecognition_amd", "-Wl,-rpath,/opt/rocm/lib"])
