@@ -1141,8 +1141,13 @@ int sr_bigram_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, co
       pos_slot[slot_off[a] + k] = a;
     }
   }
-  if (bigram_lds_bytes(W, P2) > 160 * 1024)
-    return fail(SR_ELIMIT, "lexicon too large for the bigram search's LDS image (%zu bytes > 160 KiB)", bigram_lds_bytes(W, P2));
+  {  // the dense LDS image, or -- short words -- the register layout, which needs less (viterbi_bigram.hip)
+    BigramArgs probe{};
+    probe.n_words = W; probe.ld = m->ld; probe.silence_states = n_sil;
+    for (uint32_t a2 = 0; a2 < 2 * W; a2++) probe.max_slot_states = std::max(probe.max_slot_states, slot_off[a2 + 1] - slot_off[a2]);
+    if (bigram_lds_bytes(W, P2) > 160 * 1024 && !bigram_register_layout(probe))
+      return fail(SR_ELIMIT, "lexicon too large for the bigram search's LDS image (%zu bytes > 160 KiB)", bigram_lds_bytes(W, P2));
+  }
   std::vector<float> lmT((size_t)W * W);
   for (uint32_t w = 0; w < W; w++)
     for (uint32_t h = 0; h < W; h++) lmT[(size_t)h * W + w] = lm[(size_t)w * W + h];
@@ -1222,7 +1227,10 @@ int sr_recognize_bigram_corpus(sr_model* m, sr_corpus* c, sr_bigram* b, const sr
   memcpy(ba.tdp, b->tdp, sizeof(ba.tdp));
   ba.ac_pruning = p->acoustic_pruning; ba.lm_pruning = p->lm_pruning;
   if (p->flags & ~SR_BIGRAM_DENSE_STATES) return fail(SR_EINVAL, "unknown sr_bigram_params.flags 0x%x", (unsigned)p->flags);
-  ba.max_slot_states = b->max_slot_states; ba.silence_states = b->silence_states; ba.dense_states = (p->flags & SR_BIGRAM_DENSE_STATES) ? 1u : 0u;
+  ba.max_slot_states = b->max_slot_states; ba.silence_states = b->silence_states;
+  ba.dense_states = (p->flags & SR_BIGRAM_DENSE_STATES) ? 1u : 0u;
+  if (!bigram_register_layout(ba) && bigram_lds_bytes(W, b->n_positions) > 160 * 1024)
+    return fail(SR_ELIMIT, "this lexicon runs in the register layout only (its dense LDS image would take %zu bytes > 160 KiB)", bigram_lds_bytes(W, b->n_positions));
   ba.we_slot = b->we_slot.p; ba.we_bp = b->we_bp.p; ba.we_score = b->we_score.p;
   ba.book = b->book.p; ba.book_off = b->book_off.p;
   ba.out_word = b->out_word.p; ba.out_score = b->out_score.p; ba.out_time = b->out_time.p;
