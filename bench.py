@@ -235,7 +235,10 @@ def main():
         if bg is not None:
             out["config"]["workload"] = out["config"]["workload"].replace("beam Viterbi", "bigram linear-lexicon beam search "
                                                                           "(Teaching::LinearSearch, parity unpinned)")
-            out["search"]["kernel"] = "bigram_kernel"
+            out["search"]["kernel"] = "bigram_kernel (short-word lexica: state hypotheses in registers, one lane per word and its silence copy; viterbi_bigram.hip)"
+            out["search"]["bound"] = ("latency: eight short steps per frame, each with one to three dependent global-memory round trips (word-end lists, traceback book) "
+                                      "and a barrier, one workgroup per CU (profiles/r3_bigram_steps.txt)")
+            out["search"].pop("network", None)
             out["search"].pop("achieved_GBps", None)
             out["search"].pop("bytes_per_frame", None)
         if world == 1 and not args.no_cpu_baseline:
