@@ -158,3 +158,48 @@ def test_ragged_lexica_sample_of_the_soak(tmp_path, oracle_lib):
         soak.run_case(case, seed0=41, ragged=True, tmp=str(tmp_path))
     for case in range(16):  # words of one to four positions only: the word-per-lane kernel, checked against the slot kernel too
         soak.run_case(case, seed0=47, ragged="short", tmp=str(tmp_path))
+
+
+def test_empty_and_one_frame_utterances_in_a_batch(tmp_path, oracle_lib):
+    """Utterances of 0, 1 and 2 frames between ordinary ones (Recognizer.cpp:103-232 with begin == end: no frame loop, an empty
+    word sequence): all three search kernels and the bigram search, next to the oracle."""
+    D = 12
+    lex = synth.make_lexicon(30, 3, 1)
+    spec = synth.make_mixset(lex.n_states, 2, D, seed=3)
+    mp = str(tmp_path / "m.mix")
+    synth.write_mixset(mp, spec)
+    lens = [0, 25, 1, 0, 2, 40, 0]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    feats = np.random.default_rng(4).standard_normal((int(off[-1]), D)).astype(np.float32)
+    x = synth.sample_utterance(spec, lex, [3, 7], seed=5)[:40]
+    feats[int(off[5]):int(off[5]) + len(x)] = x
+    word_off, automaton, sil = lex.flatten()
+    o = oracle_lib.Oracle(mp, D, lex, tdp=TDP, am_threshold=80.0, word_penalty=10.0)
+    W = lex.n_words
+    lm = (-np.log(np.random.default_rng(6).dirichlet(np.ones(W), size=W))).T.astype(np.float32).copy()
+    btdp = np.array([[3.0, 0.0, 30.0, 0.0], [1.0, 0.0, 40.0, 2.0]], np.float32)
+    with capi.Model.from_mixset(mp, D) as m:
+        lexh = m.lexicon(word_off, automaton, lex.silence_idx, TDP, sil)
+        c = m.upload(feats, off)
+        for general, slots in ((False, False), (False, True), (True, False)):
+            words, woff, (tbs, tbw, tbb) = c.recognize(lexh, 80.0, 10.0, capi.GMM_PREFILTER, traceback=True, general_kernel=general, slot_kernel=slots)
+            for u, n in enumerate(lens):
+                xs = feats[int(off[u]):int(off[u + 1])]
+                w, (os_, ow, ob) = o.decode(xs, traceback=True)
+                a = int(off[u]) + u
+                assert np.array_equal(w, words[int(woff[u]):int(woff[u + 1])]), (general, slots, u)
+                assert np.array_equal(tbw[a:a + n + 1], ow) and np.array_equal(tbb[a:a + n + 1], ob), (general, slots, u)
+                assert np.array_equal(tbs[a:a + n + 1].view(np.uint64), os_.view(np.uint64)), (general, slots, u)
+                if n == 0:
+                    assert len(w) == 0
+        bg = m.bigram(word_off, automaton, lex.silence_idx, lm, btdp)
+        for dense_states in (False, True):
+            gw, gs, gt, goff = c.recognize_bigram(bg, 60.0, 8.0, dense_states=dense_states)
+            for u, n in enumerate(lens):
+                dense = o.score_matrix(feats[int(off[u]):int(off[u + 1])]) if n else np.zeros((0, lex.n_states))
+                w, s_, t_ = oracle_lib.bigram_decode(dense, word_off, automaton, lex.silence_idx, lm, btdp, 60.0, 8.0)
+                a, b = int(goff[u]), int(goff[u + 1])
+                assert np.array_equal(gw[a:b], w) and np.array_equal(gt[a:b], t_), (dense_states, u)
+                assert np.array_equal(gs[a:b].view(np.uint32), s_.view(np.uint32)), (dense_states, u)
+        bg.close(); c.close(); lexh.close()
+    o.close()
