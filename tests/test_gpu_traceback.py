@@ -203,3 +203,35 @@ def test_empty_and_one_frame_utterances_in_a_batch(tmp_path, oracle_lib):
                 assert np.array_equal(gs[a:b].view(np.uint32), s_.view(np.uint32)), (dense_states, u)
         bg.close(); c.close(); lexh.close()
     o.close()
+
+
+def test_longest_utterance_the_back_pointers_allow(tmp_path, oracle_lib):
+    """Book::bkp is a uint16_t (Recognizer.hpp:75-89): the library takes utterances of up to 65 535 frames (one frame more is
+    SR_ELIMIT at upload: the reference's back pointers would wrap).  The maximum itself, a tiny lexicon, the three kernels against
+    the oracle -- back pointers up to 65 534."""
+    D = 4
+    lex = synth.make_lexicon(2, 3, 1)
+    spec = synth.make_mixset(lex.n_states, 2, D, seed=8)
+    mp = str(tmp_path / "m.mix")
+    synth.write_mixset(mp, spec)
+    T = 65_535
+    feats = np.random.default_rng(9).standard_normal((T, D)).astype(np.float32)
+    for i, start in enumerate(range(0, T - 400, 1500)):  # a word now and then
+        x = synth.sample_utterance(spec, lex, [1 + i % 2], seed=100 + i)
+        feats[start:start + len(x)] = x
+    word_off, automaton, sil = lex.flatten()
+    o = oracle_lib.Oracle(mp, D, lex, tdp=TDP, am_threshold=100.0, word_penalty=10.0)
+    w, (os_, ow, ob) = o.decode(feats, traceback=True)
+    o.close()
+    assert ob.max() > 65_000 and len(w) > 20
+    with capi.Model.from_mixset(mp, D) as m:
+        lexh = m.lexicon(word_off, automaton, lex.silence_idx, TDP, sil)
+        with pytest.raises(capi.SrError) as e:
+            m.upload(np.zeros((T + 1, D), np.float32), np.array([0, T + 1], np.uint64))
+        assert e.value.code == -4  # SR_ELIMIT
+        c = m.upload(feats, np.array([0, T], np.uint64))
+        for general, slots in ((False, False), (False, True), (True, False)):
+            words, woff, (tbs, tbw, tbb) = c.recognize(lexh, 100.0, 10.0, capi.GMM_EXACT, traceback=True, general_kernel=general, slot_kernel=slots)
+            assert np.array_equal(words, w), (general, slots)
+            assert np.array_equal(tbw, ow) and np.array_equal(tbb, ob) and np.array_equal(tbs.view(np.uint64), os_.view(np.uint64)), (general, slots)
+        c.close(); lexh.close()
