@@ -207,9 +207,25 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
     // <= score_e + rowmax[h_e], so U = min_e (score_e + rowmax[h_e]) bounds all final start scores; a word end with
     // score_e + rowmin[h_e] > U can never produce "newScore < start[w]" (float addition is monotone, so the bounds hold
     // for the rounded sums).  With a beam of 200 over LM scores spanning ~10 this drops most of the E x W work.
+    // The merged word-end list lives in HBM and steps 1 and 2 walk it five times; thread k owns the contiguous entries
+    // [k * ce1, (k + 1) * ce1) in every one of those walks (n_we <= W <= KW * 1024: at most KW entries), so it reads them ONCE, into
+    // registers: one global round trip (~2 000 cycles) instead of five.
+    const uint32_t ce1 = (n_we + kBgThreads - 1) / kBgThreads;
+    const uint32_t e1_lo = tid * ce1 < n_we ? tid * ce1 : n_we, e1_hi = (e1_lo + ce1 < n_we) ? e1_lo + ce1 : n_we;
+    uint32_t m_raw[KW], m_bp[KW];
+    float m_sc[KW];
+#pragma unroll
+    for (int i = 0; i < KW; i++) {
+      const uint32_t e = e1_lo + (uint32_t)i;
+      const bool in = e < e1_hi;
+      m_raw[i] = in ? we_slot[cur][e] : 0u;
+      m_sc[i] = in ? we_score[cur][e] : 0.0f;
+      m_bp[i] = in ? we_bp[cur][e] : 0u;
+    }
     float lu = kFltMax;
-    for (uint32_t e = tid; e < n_we; e += kBgThreads)
-      lu = fminf(lu, we_score[cur][e] + rowmax(map_copy(we_slot[cur][e] & kSlotMask)));
+#pragma unroll
+    for (int i = 0; i < KW; i++)
+      if (e1_lo + (uint32_t)i < e1_hi) lu = fminf(lu, m_sc[i] + rowmax(map_copy(m_raw[i] & kSlotMask)));
     const float U = wg_min(lu, red_tmp);
     // staging buffer: the dedicated 256 entries, or -- for a big lexicon -- the idle half of the active-list double
     // buffer (it is rewritten from scratch in step 4), up to one entry per thread: fewer passes and barriers
@@ -222,18 +238,18 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
     // One pass over the word ends, thread k owning the contiguous entries [k * ce, (k + 1) * ce): the silence-copy transitions, the
     // skip test, and an ordered scan that gives every survivor its place in the staging buffer (round 2 staged chunk after chunk
     // of the list, three barriers per chunk, although on most frames one or two word ends survive the skip test at all).
-    const uint32_t ce1 = (n_we + kBgThreads - 1) / kBgThreads;
-    const uint32_t e1_lo = tid * ce1 < n_we ? tid * ce1 : n_we, e1_hi = (e1_lo + ce1 < n_we) ? e1_lo + ce1 : n_we;
     uint32_t n_keep = 0;
-    for (uint32_t e = e1_lo; e < e1_hi; e++) {
-      const uint32_t raw = we_slot[cur][e], sl = raw & kSlotMask;
-      const float sc_e = we_score[cur][e];
+#pragma unroll
+    for (int i = 0; i < KW; i++) {
+      if (!(e1_lo + (uint32_t)i < e1_hi)) continue;
+      const uint32_t raw = m_raw[i], sl = raw & kSlotMask;
+      const float sc_e = m_sc[i];
       // transition into the silence copy of the word that ended (no LM cost); where the merge left the same word end
       // twice in the list, addEntryStateHypothesis (:257-268) keeps the LATER start hypothesis
       if (sl < W && !(raw & kShadowed)) {
         const uint32_t c = sil_copy(sl);
         en_score[c] = sc_e;
-        en_bp[c] = we_bp[cur][e];
+        en_bp[c] = m_bp[i];
       }
       n_keep += !(sc_e + rowmin(map_copy(sl)) > U) ? 1u : 0u;
     }
@@ -242,14 +258,16 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
     for (uint32_t r0 = 0; r0 < ne_all; r0 += stg_cap) {  // (one round unless more word ends survive than the staging buffer holds)
       if (r0) __syncthreads();  // the previous round's rows have been read
       uint32_t pos = keep_pos;
-      for (uint32_t e = e1_lo; e < e1_hi; e++) {
-        const uint32_t sl = we_slot[cur][e] & kSlotMask, h = map_copy(sl);
-        const float sc_e = we_score[cur][e];
+#pragma unroll
+      for (int i = 0; i < KW; i++) {
+        if (!(e1_lo + (uint32_t)i < e1_hi)) continue;
+        const uint32_t sl = m_raw[i] & kSlotMask, h = map_copy(sl);
+        const float sc_e = m_sc[i];
         if (!(sc_e + rowmin(h) > U)) {
           if (pos >= r0 && pos - r0 < stg_cap) {
             stg[3 * (pos - r0)] = h;
             stg[3 * (pos - r0) + 1] = __float_as_uint(sc_e);
-            stg[3 * (pos - r0) + 2] = we_bp[cur][e];
+            stg[3 * (pos - r0) + 2] = m_bp[i];
           }
           pos++;
         }
@@ -317,11 +335,11 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
       }
       // (b) silence copies, in the order of the word ends that start them.  (a) and (b) touch disjoint slots -- words other than
       // silence there, silence and the copies here -- so both are counted first and ONE scan (16 bits each) places both
-      const uint32_t ce = (n_we + kBgThreads - 1) / kBgThreads;
-      const uint32_t e_lo = tid * ce < n_we ? tid * ce : n_we, e_hi = (e_lo + ce < n_we) ? e_lo + ce : n_we;
       uint32_t cnt_b = 0;
-      for (uint32_t e = e_lo; e < e_hi; e++) {
-        const uint32_t raw = we_slot[cur][e], sl = raw & kSlotMask;
+#pragma unroll
+      for (int i = 0; i < KW; i++) {  // (the thread's entries of the merged list: in registers since step 1)
+        if (!(e1_lo + (uint32_t)i < e1_hi)) continue;
+        const uint32_t raw = m_raw[i], sl = raw & kSlotMask;
         if (sl < W && !(raw & kRepeat)) {  // (a repeated word end activates nothing new: its first occurrence did)
           const uint32_t c = sil_copy(sl);
           const bool ins = en_score[c] < lm_thr;
@@ -336,8 +354,10 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
         if (w != sil && en_score[w] < __builtin_inff() && !active[w]) { L[lcur][pos++] = (uint16_t)w; active[w] = 1; }
       n_L += total & 0xFFFFu;
       pos = n_L + (ex >> 16);
-      for (uint32_t e = e_lo; e < e_hi; e++) {
-        const uint32_t raw = we_slot[cur][e], sl = raw & kSlotMask;
+#pragma unroll
+      for (int i = 0; i < KW; i++) {
+        if (!(e1_lo + (uint32_t)i < e1_hi)) continue;
+        const uint32_t raw = m_raw[i], sl = raw & kSlotMask;
         if (sl < W && !(raw & kRepeat)) {
           const uint32_t c = sil_copy(sl);
           if (en_score[c] < __builtin_inff() && !active[c]) { L[lcur][pos++] = (uint16_t)c; active[c] = 1; }
@@ -597,7 +617,7 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
     }
     __syncthreads();
     uint32_t nh = 0;
-    for (uint32_t e = tid; e < tot_ends; e += kBgThreads)
+    for (uint32_t e = tid; e < tot_ends; e += kBgThreads)  // (the second walk hits L1: caching the entries in registers was slower, 35.5 vs 34.4 ms)
       if (first[map_copy(we_slot[nxt][e])] == e) nh++;
     uint32_t n_hist;
     (void)wg_excl_scan(nh, scan_tmp, &n_hist);
