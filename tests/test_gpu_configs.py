@@ -27,6 +27,12 @@ def test_cfg3_default_pairing_prefilter_plus_fast_decoder(tmp_path, oracle_lib):
     word_off, automaton, sil_state = lex.flatten()
     with capi.Model.from_mixset(mp, 39) as m:
         lexh = m.lexicon(word_off, automaton, lex.silence_idx, TDP, sil_state)
+        assert lexh.describe() == "words 3 x 512 plain 3"  # 1333 plain words + silence: 22 groups of 64 on 8 waves, three per lane
+        sl = synth.sietill_lexicon()                        # the reference's own lexicon (18-24 positions per word): the slot kernel
+        swo, sau, ssil = sl.flatten()
+        slh = m.lexicon(swo, sau, sl.silence_idx, TDP, ssil)
+        assert slh.describe().startswith("slots (")
+        slh.close()
         corpus = m.upload(feats, off)
         words, woff, (tbs, tbw, tbb) = corpus.recognize(lexh, 200.0, 10.0, capi.GMM_PREFILTER, traceback=True)
         w2, o2, (s2, ww2, b2) = corpus.recognize(lexh, 200.0, 10.0, capi.GMM_EXACT, traceback=True, general_kernel=True)
