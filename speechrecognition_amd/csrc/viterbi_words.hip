@@ -1,6 +1,7 @@
 // viterbi_words.hip -- the beam Viterbi decoder (Recognizer::recognizeSequence_pruned, sietill/Recognizer.cpp:103-232) for
 // lexica of SHORT words (every word at most four positions: the synthetic configurations of SURVEY 8d are silence + W words of
-// three states).  One workgroup per utterance, one LANE per word (NW words per lane for W > 1024).
+// three states).  One workgroup per utterance, one LANE per word (NW words per lane: the host picks NW so that a workgroup has
+// at most 8 waves where it can -- two workgroups then share a CU).
 //
 // In a linear whole-word lexicon every in-word transition stays inside its word (loop, forward, skip: Recognizer.cpp:160-186),
 // and the word-boundary transition reaches a word only through the minimum over the surviving word ends (viterbi_decode.hip, the
@@ -40,7 +41,7 @@ static constexpr uint32_t kWSilWord = 8u, kWFirstSil = 16u, kWSilStates = 0xF00u
 
 static constexpr uint32_t kWordsCellBytes = 1024;  // minima and first-index cells; the row buffers follow, 1 KB aligned
 
-// Lanes take their words from an ORDER the host chose (srgpu_api.cpp: build_word_order).  A (wave, k) GROUP of 64 word slots
+// Lanes take their words from an ORDER the host chose (srgpu_api.cpp: sr_lexicon_create).  A (wave, k) GROUP of 64 word slots
 // holds words of one kind -- the host pads every kind to whole groups -- and runs that kind's code:
 //   plain    exactly L positions, not the silence word, no silence state: every transition penalty a scalar, the role of
 //            every position known at compile time -- a third of the general path's instructions.  In SURVEY 8d's lexica
