@@ -361,7 +361,8 @@ def prefilter_report(args, prof, n_frames, D, S):
     launches = max(1, prof["gmm_launches"])
     p_ms, g_ms = prof["prefilter_ms"] / launches, prof["gmm_ms"] / launches
     k = 32 * ((2 * D + 3 + 31) // 32)
-    p_flops = 2.0 * k * (32 * 4 * ((S + 3) // 4)) * n_frames  # executed: one fp16 product, K and states padded
+    cs = 1 if args.mix <= 32 else 2 if args.mix <= 64 else 4   # a mixture of more than 32 densities is cut into 2 or 4 chunks of 32 (pseudo-states)
+    p_flops = 2.0 * k * (32 * 4 * ((S * cs + 3) // 4)) * n_frames  # executed: one fp16 product, K and (pseudo-)states padded
     p_useful = 2.0 * (2 * D + 3) * S * args.mix * n_frames     # useful: K = 2 D + 3 per real density
     dense = 4.0 * D * S * args.mix * n_frames
     # matrix-pipe busy share from the committed counters (same workload, same kernel sources): SQ_VALU_MFMA_BUSY_CYCLES over
