@@ -115,11 +115,15 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
   uint8_t* active = reinterpret_cast<uint8_t*>(L[1] + W2);    // [2W]
   // register layout: the LM row bounds of the skip test (2 x W floats: from global memory they are a dependent round trip in
   // three passes of step 1), then the frame's emission costs (ld doubles), 1 KB aligned
-  float* lm_lo_lds = reinterpret_cast<float*>(smem + ((bigram_lds_small(a.n_words) + 15u) & ~(size_t)15u));
-  float* lm_hi_lds = lm_lo_lds + W;
+  // -- as bf16, the minimum rounded down and the maximum up: bounds stay bounds, the skip test stays exact (it only drops word ends
+  // that cannot win), and the 2 x 2W bytes saved hold the NEW word-end list of step 4 (slots only: score and back pointer are
+  // fin_score / fin_bp of the slot), which steps 5 and 6 then read from LDS instead of from the global work space
+  uint16_t* lm_lo_lds = reinterpret_cast<uint16_t*>(smem + ((bigram_lds_small(a.n_words) + 15u) & ~(size_t)15u));
+  uint16_t* lm_hi_lds = lm_lo_lds + W;
+  uint16_t* pm_slot = lm_hi_lds + W;  // [2W]
   unsigned char* row_lds = smem + bigram_lds_row_off(a.n_words);
-  auto rowmin = [&](uint32_t h) -> float { if constexpr (REGS) return lm_lo_lds[h]; else return a.lm_rowmin[h]; };
-  auto rowmax = [&](uint32_t h) -> float { if constexpr (REGS) return lm_hi_lds[h]; else return a.lm_rowmax[h]; };
+  auto rowmin = [&](uint32_t h) -> float { if constexpr (REGS) return __uint_as_float((uint32_t)lm_lo_lds[h] << 16); else return a.lm_rowmin[h]; };
+  auto rowmax = [&](uint32_t h) -> float { if constexpr (REGS) return __uint_as_float((uint32_t)lm_hi_lds[h] << 16); else return a.lm_rowmax[h]; };
   float* fin_score = en_score;                                // [2W] final-state score / back pointer of the slots whose word end survived
   uint32_t* fin_bp = en_bp;                                   //      (written in step 4, read by its compaction; the entries are consumed by then)
 
@@ -162,7 +166,18 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
     }
   };
   if (REGS) {
-    for (uint32_t i = tid; i < W; i += kBgThreads) { lm_lo_lds[i] = a.lm_rowmin[i]; lm_hi_lds[i] = a.lm_rowmax[i]; }
+    for (uint32_t i = tid; i < W; i += kBgThreads) {
+      // float -> bf16 by truncation moves a value toward zero: down for x >= 0, up for x < 0; step the other way where asked
+      auto to_bf16 = [](float x, bool up) -> uint16_t {
+        const uint32_t b = __float_as_uint(x);
+        if ((b & 0x7FFFFFFFu) > 0x7F800000u) return (uint16_t)0x7FC0u;  // NaN stays NaN: nothing is skipped against it
+        uint32_t t = b >> 16;
+        if ((b & 0xFFFFu) && (bool)(b >> 31) != up) t += 1u;  // grow the magnitude: further down for negatives, further up for positives
+        return (uint16_t)t;
+      };
+      lm_lo_lds[i] = to_bf16(a.lm_rowmin[i], false);
+      lm_hi_lds[i] = to_bf16(a.lm_rowmax[i], true);
+    }
 #pragma unroll
     for (int k = 0; k < KSR; k++) {
       const uint32_t w = tid + (uint32_t)k * kBgThreads;
@@ -588,12 +603,11 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
       active[sl] = 1;
       L[lcur ^ 1][pa++] = (uint16_t)sl;
       if (fa & 4u) {  // the final state survived: a word end, carrying the exit-penalised score
-        we_slot[nxt][pe] = sl;
         if (REGS) {
-          we_score[nxt][pe] = fin_score[sl] + exit_pen[is_sil(sl)];
-          we_bp[nxt][pe] = fin_bp[sl];
+          pm_slot[pe] = (uint16_t)sl;  // (score = fin_score[sl] + exit penalty, back pointer = fin_bp[sl]: steps 5 and 6 look them up)
         } else {
           const uint32_t last = a.slot_off[sl + 1] - 1;
+          we_slot[nxt][pe] = sl;
           we_score[nxt][pe] = st_score[last] + exit_pen[is_sil(sl)];
           we_bp[nxt][pe] = st_bp[last];
         }
@@ -606,47 +620,96 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
 
     // ---- 5 mergeSilenceToBigramNodes.  first[h] / last[h] = first / last index of a word end with history h; the
     // reference writes the better of the (at most two) into the FIRST index and then keeps list[0 .. #histories) --------
-    uint32_t* first = reinterpret_cast<uint32_t*>(en_score);  // [W] (entries are consumed; rebuilt next frame)
-    uint32_t* last = en_bp;                                   // [W]
-    for (uint32_t h = tid; h < W; h += kBgThreads) { first[h] = 0xFFFFFFFFu; last[h] = 0u; }
-    __syncthreads();
-    for (uint32_t e = tid; e < tot_ends; e += kBgThreads) {
-      const uint32_t h = map_copy(we_slot[nxt][e]);
-      atomicMin(&first[h], e);
-      atomicMax(&last[h], e);
-    }
-    __syncthreads();
-    uint32_t nh = 0;
-    for (uint32_t e = tid; e < tot_ends; e += kBgThreads)  // (the second walk hits L1: caching the entries in registers was slower, 35.5 vs 34.4 ms)
-      if (first[map_copy(we_slot[nxt][e])] == e) nh++;
     uint32_t n_hist;
-    (void)wg_excl_scan(nh, scan_tmp, &n_hist);
-    // ---- 6 addBookKeepingEntries for the kept word ends e = 0 .. n_hist-1, in list order -----------------------------
-    if ((uint64_t)n_book + n_hist > book_cap) { overflow = true; break; }  // workgroup-uniform
-    for (uint32_t e = tid; e < n_hist; e += kBgThreads) {
-      const uint32_t h = map_copy(we_slot[nxt][e]);
-      uint32_t src = e, mark = 0;
-      if (first[h] == e) {
-        const uint32_t j = last[h];
-        if (j != e && we_score[nxt][j] <= we_score[nxt][e]) {  // <=: the later one wins a tie
-          src = j;
-          if (j < n_hist) mark = kShadowed;  // ... and stays in the list at its own index too
+    if constexpr (REGS) {
+      // A history h has at most two word ends: slot h (the word) and slot W + h (its silence copy).  pos[slot] = the slot's index in
+      // the new list (0xFFFF: not a word end this frame), kept in the idle half of the active-list double buffer: first and last
+      // are the smaller and the larger of the two positions -- no atomics, and every look-up of steps 5 and 6 is an LDS read.
+      uint16_t* pos = L[lcur ^ 1];
+      for (uint32_t i = tid; i < W2; i += kBgThreads) pos[i] = 0xFFFFu;
+      __syncthreads();
+      for (uint32_t e = tid; e < tot_ends; e += kBgThreads) pos[pm_slot[e]] = (uint16_t)e;
+      __syncthreads();
+      auto first_last = [&](uint32_t h, uint32_t* fi, uint32_t* la) {
+        const uint32_t p1 = pos[h], p2 = h != sil ? (uint32_t)pos[W + h] : 0xFFFFu;
+        *fi = p1 < p2 ? p1 : p2;
+        *la = p1 == 0xFFFFu ? p2 : p2 == 0xFFFFu ? p1 : (p1 > p2 ? p1 : p2);
+      };
+      auto we_sc = [&](uint32_t e) -> float { const uint32_t sl = pm_slot[e]; return fin_score[sl] + exit_pen[is_sil(sl)]; };
+      uint32_t nh = 0;
+      for (uint32_t e = tid; e < tot_ends; e += kBgThreads) {
+        uint32_t fi, la;
+        first_last(map_copy(pm_slot[e]), &fi, &la);
+        if (fi == e) nh++;
+      }
+      (void)wg_excl_scan(nh, scan_tmp, &n_hist);
+      // ---- 6 addBookKeepingEntries for the kept word ends e = 0 .. n_hist-1, in list order ---------------------------
+      if ((uint64_t)n_book + n_hist > book_cap) { overflow = true; break; }  // workgroup-uniform
+      for (uint32_t e = tid; e < n_hist; e += kBgThreads) {
+        uint32_t fi, la;
+        first_last(map_copy(pm_slot[e]), &fi, &la);
+        uint32_t src = e, mark = 0;
+        if (fi == e) {
+          if (la != e && we_sc(la) <= we_sc(e)) {  // <=: the later one wins a tie
+            src = la;
+            if (la < n_hist) mark = kShadowed;  // ... and stays in the list at its own index too
+          }
+        } else {
+          if (we_sc(e) <= we_sc(fi)) mark = kRepeat;  // (fi < e < n_hist) did index fi take over this entry?
         }
-      } else {
-        const uint32_t i = first[h];  // (i < e < n_hist) did index i take over this entry?
-        if (we_score[nxt][e] <= we_score[nxt][i]) mark = kRepeat;
+        const uint32_t sl = pm_slot[src];
+        const float sc = fin_score[sl] + exit_pen[is_sil(sl)];
+        uint32_t bp = fin_bp[sl];
+        if (sl == sil) {  // avoid chains of silence (:410-415); entries store acoustic words, copies count as silence
+          const uint4 prev = book[bp];
+          if (prev.x == sil) bp = prev.z;
+        }
+        const uint32_t nb = n_book + e;
+        book[nb] = make_uint4(ac_word(sl), __float_as_uint(sc), bp, (uint32_t)t);
+        we_slot[cur][e] = sl | mark; we_score[cur][e] = sc; we_bp[cur][e] = nb;
       }
-      const uint32_t sl = we_slot[nxt][src];
-      const float sc = we_score[nxt][src];
-      uint32_t bp = we_bp[nxt][src];
-      if (sl == sil) {  // avoid chains of silence (:410-415); entries store acoustic words, copies count as silence
-        const uint4 prev = book[bp];
-        if (prev.x == sil) bp = prev.z;
+    } else {
+      uint32_t* first = reinterpret_cast<uint32_t*>(en_score);  // [W] (entries are consumed; rebuilt next frame)
+      uint32_t* last = en_bp;                                   // [W]
+      for (uint32_t h = tid; h < W; h += kBgThreads) { first[h] = 0xFFFFFFFFu; last[h] = 0u; }
+      __syncthreads();
+      for (uint32_t e = tid; e < tot_ends; e += kBgThreads) {
+        const uint32_t h = map_copy(we_slot[nxt][e]);
+        atomicMin(&first[h], e);
+        atomicMax(&last[h], e);
       }
-      const uint32_t nb = n_book + e;
-      book[nb] = make_uint4(ac_word(sl), __float_as_uint(sc), bp, (uint32_t)t);
-      // the merged list for the next frame goes to the other buffer (reads above are from `nxt`, writes to `cur`)
-      we_slot[cur][e] = sl | mark; we_score[cur][e] = sc; we_bp[cur][e] = nb;
+      __syncthreads();
+      uint32_t nh = 0;
+      for (uint32_t e = tid; e < tot_ends; e += kBgThreads)  // (the second walk hits L1: caching the entries in registers was slower, 35.5 vs 34.4 ms)
+        if (first[map_copy(we_slot[nxt][e])] == e) nh++;
+      (void)wg_excl_scan(nh, scan_tmp, &n_hist);
+      // ---- 6 addBookKeepingEntries for the kept word ends e = 0 .. n_hist-1, in list order -----------------------------
+      if ((uint64_t)n_book + n_hist > book_cap) { overflow = true; break; }  // workgroup-uniform
+      for (uint32_t e = tid; e < n_hist; e += kBgThreads) {
+        const uint32_t h = map_copy(we_slot[nxt][e]);
+        uint32_t src = e, mark = 0;
+        if (first[h] == e) {
+          const uint32_t j = last[h];
+          if (j != e && we_score[nxt][j] <= we_score[nxt][e]) {  // <=: the later one wins a tie
+            src = j;
+            if (j < n_hist) mark = kShadowed;  // ... and stays in the list at its own index too
+          }
+        } else {
+          const uint32_t i = first[h];  // (i < e < n_hist) did index i take over this entry?
+          if (we_score[nxt][e] <= we_score[nxt][i]) mark = kRepeat;
+        }
+        const uint32_t sl = we_slot[nxt][src];
+        const float sc = we_score[nxt][src];
+        uint32_t bp = we_bp[nxt][src];
+        if (sl == sil) {  // avoid chains of silence (:410-415); entries store acoustic words, copies count as silence
+          const uint4 prev = book[bp];
+          if (prev.x == sil) bp = prev.z;
+        }
+        const uint32_t nb = n_book + e;
+        book[nb] = make_uint4(ac_word(sl), __float_as_uint(sc), bp, (uint32_t)t);
+        // the merged list for the next frame goes to the other buffer (reads above are from `nxt`, writes to `cur`)
+        we_slot[cur][e] = sl | mark; we_score[cur][e] = sc; we_bp[cur][e] = nb;
+      }
     }
     n_book += n_hist;
     n_we = n_hist;
