@@ -121,6 +121,7 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
   uint16_t* lm_lo_lds = reinterpret_cast<uint16_t*>(smem + ((bigram_lds_small(a.n_words) + 15u) & ~(size_t)15u));
   uint16_t* lm_hi_lds = lm_lo_lds + W;
   uint16_t* pm_slot = lm_hi_lds + W;  // [2W]
+  uint32_t* n_pairs = reinterpret_cast<uint32_t*>(active + ((W2 + 3u) & ~3u));  // histories whose word AND silence copy end this frame
   unsigned char* row_lds = smem + bigram_lds_row_off(a.n_words);
   auto rowmin = [&](uint32_t h) -> float { if constexpr (REGS) return __uint_as_float((uint32_t)lm_lo_lds[h] << 16); else return a.lm_rowmin[h]; };
   auto rowmax = [&](uint32_t h) -> float { if constexpr (REGS) return __uint_as_float((uint32_t)lm_hi_lds[h] << 16); else return a.lm_rowmax[h]; };
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
   for (uint64_t t = 1; t <= T; t++) {
     // ---- 1 bigramRecombination + LM beam ------------------------------------------------------------------------
     for (uint32_t i = W + tid; i < W2; i += kBgThreads) en_score[i] = __builtin_inff();
-    if (tid == 0) en_score[sil] = __builtin_inff();
+    if (tid == 0) { en_score[sil] = __builtin_inff(); if (REGS) *n_pairs = 0; }
     float my_score[KW];  // words per thread: W <= KW * kBgThreads
     uint32_t my_bp[KW];
 #pragma unroll
@@ -318,7 +319,8 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
         }
       }
     }
-    __syncthreads();
+    // (no barrier here: the words' entries written next are read by nobody before the barrier below, and the staging buffer the
+    // loop above read is not among them)
     float lmin = kFltMax;
 #pragma unroll
     for (int k = 0; k < KW; k++) {
@@ -329,7 +331,8 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
         lmin = fminf(lmin, my_score[k]);
       }
     }
-    __syncthreads();
+    // (no barrier here either: the copies' entries and en_score[sil] read next were written before the scan's barrier above; the
+    // words' entries just written are first read in step 2, behind the barrier inside wg_min)
     for (uint32_t i = W + tid; i < W2; i += kBgThreads) lmin = fminf(lmin, en_score[i]);
     if (tid == 0) lmin = fminf(lmin, en_score[sil]);
     const float best_start = wg_min(lmin, red_tmp);
@@ -565,6 +568,7 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
           }
           active[W + w] = (uint8_t)((active[W + w] & 1u) | cflags);
           if (cflags) { fin_score[W + w] = rc_sc[k]; fin_bp[W + w] = rc_bp[k]; }
+          if ((flags & 4u) && cflags) atomicAdd(n_pairs, 1u);  // both word ends of this history survive: the merge keeps one entry for them
         }
       }
     } else {
@@ -625,24 +629,19 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
       // A history h has at most two word ends: slot h (the word) and slot W + h (its silence copy).  pos[slot] = the slot's index in
       // the new list (0xFFFF: not a word end this frame), kept in the idle half of the active-list double buffer: first and last
       // are the smaller and the larger of the two positions -- no atomics, and every look-up of steps 5 and 6 is an LDS read.
+      // The buffer is not cleared: whatever a slot's cell holds (an older frame's position, a slot number of the old active list),
+      // it is this frame's position of slot s if and only if it is below the list's length and the list holds s there.
       uint16_t* pos = L[lcur ^ 1];
-      for (uint32_t i = tid; i < W2; i += kBgThreads) pos[i] = 0xFFFFu;
-      __syncthreads();
       for (uint32_t e = tid; e < tot_ends; e += kBgThreads) pos[pm_slot[e]] = (uint16_t)e;
       __syncthreads();
+      auto pos_of = [&](uint32_t s_) -> uint32_t { const uint32_t g = pos[s_]; return (g < tot_ends && pm_slot[g] == s_) ? g : 0xFFFFu; };
       auto first_last = [&](uint32_t h, uint32_t* fi, uint32_t* la) {
-        const uint32_t p1 = pos[h], p2 = h != sil ? (uint32_t)pos[W + h] : 0xFFFFu;
+        const uint32_t p1 = pos_of(h), p2 = h != sil ? pos_of(W + h) : 0xFFFFu;
         *fi = p1 < p2 ? p1 : p2;
         *la = p1 == 0xFFFFu ? p2 : p2 == 0xFFFFu ? p1 : (p1 > p2 ? p1 : p2);
       };
       auto we_sc = [&](uint32_t e) -> float { const uint32_t sl = pm_slot[e]; return fin_score[sl] + exit_pen[is_sil(sl)]; };
-      uint32_t nh = 0;
-      for (uint32_t e = tid; e < tot_ends; e += kBgThreads) {
-        uint32_t fi, la;
-        first_last(map_copy(pm_slot[e]), &fi, &la);
-        if (fi == e) nh++;
-      }
-      (void)wg_excl_scan(nh, scan_tmp, &n_hist);
+      n_hist = tot_ends - *n_pairs;  // #histories = #word ends - #histories with two of them (counted by their owners in step 4)
       // ---- 6 addBookKeepingEntries for the kept word ends e = 0 .. n_hist-1, in list order ---------------------------
       if ((uint64_t)n_book + n_hist > book_cap) { overflow = true; break; }  // workgroup-uniform
       for (uint32_t e = tid; e < n_hist; e += kBgThreads) {
