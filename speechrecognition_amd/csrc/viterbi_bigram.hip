@@ -366,6 +366,10 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
         }
       }
       uint32_t total;
+      // register layout: this scan's barrier is the last one before step 3 -- the entries are final (the LM beam was applied in the
+      // counting passes above), step 3 reads nothing of what the placement below writes (the list and the membership flags are next
+      // read behind step 3's own reduction barrier), and the frame's emission row is published here
+      if (REGS) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of the row have landed
       const uint32_t ex = wg_excl_scan(cnt | (cnt_b << 16), scan_tmp, &total);
       uint32_t pos = n_L + (ex & 0xFFFFu);
       for (uint32_t w = w_lo; w < w_hi; w++)
@@ -382,8 +386,7 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
         }
       }
       n_L += total >> 16;
-      if (REGS) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of the frame's row have landed; the barrier publishes them
-      __syncthreads();
+      if (!REGS) __syncthreads();
     }
 
     // ---- 3 expandHypotheses + addAcousticScores, one thread per POSITION (round 3) --------------------------------------
