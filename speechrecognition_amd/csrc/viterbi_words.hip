@@ -102,6 +102,13 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
     const uint32_t flags = info[k] & (7u | kWSilWord | kWFirstSil | kWSilStates);
     kind[k] = real[k] == 0 ? kGSkip : __all(!in || flags == (uint32_t)L) ? kGPlain : __all(!in || (info[k] & 7u) == 1u) ? kGSingle : kGGeneral;
   }
+  // The host puts a general group into slot row k = 0 of a wave of its own (srgpu_api.cpp), so only k = 0 carries the registers of
+  // a fourth position and the general code.  (A general group anywhere else -- not something sr_lexicon_create produces -- sends the
+  // utterance to the replay kernel.)
+  bool misplaced = false;
+#pragma unroll
+  for (int k = 1; k < NW; k++) misplaced |= kind[k] == kGGeneral;
+  if (!GEN) misplaced |= kind[0] == kGGeneral;
   if (tid < 12) e_first[tid] = 0xFFFFFFFFu;
   if (tid < 3) { c_best[tid] = kInfF; c_we[tid] = kInfF; c_widx[tid] = 0xFFFFFFFFu; }
   if (tid == 12) *s_bad = 0;
@@ -129,7 +136,7 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
   if (T > 0) { issue_row(1); __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0)
   __syncthreads();
 
-  uint64_t bad = 0;  // lanes that met an emission cost that is not >= 0 (scalar mask, looked at after the last frame)
+  uint64_t bad = misplaced ? ~0ull : 0ull;  // lanes that met an emission cost that is not >= 0 (scalar mask, looked at after the last frame)
   // the lane that may own traceback[t]: it held the word-end minimum of frame t; settled by the atomic, written one barrier later
   bool pend = false;
   uint32_t pend_o = 0, pend_w = 0, pend_b = 0;
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
       if (kind[k] == kGSkip) continue;
 #pragma unroll
       for (int p = 0; p < NPA; p++)
-        if (kind[k] == kGGeneral || (kind[k] == kGPlain && p < L) || p == 0) e[k][p] = *reinterpret_cast<const double*>(row_l + st[k][p]);
+        if ((GEN && k == 0 && kind[k] == kGGeneral) || (kind[k] == kGPlain && p < L) || p == 0) e[k][p] = *reinterpret_cast<const double*>(row_l + st[k][p]);
     }
 #pragma unroll
     for (int k = 0; k < NW; k++) {
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
         sc[k][0] = n_b; bk[k][0] = n_b < kInfF ? bkp_new : 0u;
         my_best = dmin(my_best, dmin(n_b, dead));
         my_we = dmin(my_we, n_b);
-      } else if (GEN && kind[k] == kGGeneral) {
+      } else if (GEN && k == 0 && kind[k] == kGGeneral) {
         // ---- general: 0 .. 4 positions per lane, silence word, silence states -------------------------------------------------
         uint32_t inf_k = info[k];
         asm volatile("" : "+v"(inf_k));
@@ -307,7 +314,7 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
       if (kind[k] == kGSkip) continue;
 #pragma unroll
       for (int p = 0; p < NPA; p++) {
-        if ((kind[k] == kGPlain && p >= L) || (kind[k] == kGSingle && p >= 1)) continue;
+        if ((k > 0 && p >= L) || (kind[k] == kGPlain && p >= L) || (kind[k] == kGSingle && p >= 1)) continue;
         double v = sc[k][p];
         if (v > limit) v = kInfF;  // :194-196
         sc[k][p] = v;
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
         v_end[k] = sc[k][L - 1]; b_end[k] = bk[k][L - 1];
       } else if (kind[k] == kGSingle) {
         v_end[k] = sc[k][0]; b_end[k] = bk[k][0];
-      } else {
+      } else if (k == 0) {
         const uint32_t n = info[k] & 7u;
 #pragma unroll
         for (int p = 0; p < NPA; p++)
