@@ -83,7 +83,7 @@ def run_case(case, seed0=0, ragged=False, tmp=None):
             assert np.array_equal(stp[int(off[u]):int(off[u + 1])], s_) and costp[u] == c_, (tag, "align pruned", u)
         # bigram search on the same model (the automaton positions are the lexicon's mixtures)
         nW = lex.n_words
-        if nW <= 400:
+        if nW <= 400 or n_utts <= 9:  # (big lexica -- two and three words per lane in the register layout -- on the small batches only: the oracle's cost)
             lm = (-np.log(rng.dirichlet(np.ones(nW), size=nW))).T.astype(np.float32).copy()
             tdp = np.array([[3.0, 0.0, 30.0, float(rng.choice([0.0, 5.0]))], [1.0, 0.0, 40.0, 2.0]], np.float32)
             acp = float(rng.choice([30.0, 120.0, pyoracle.FLT_MAX]))
