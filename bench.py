@@ -227,6 +227,7 @@ def main():
             "roofline": gmm_roofline(args, prof, n_frames, D, S),
             "search": search_report(args, prof, S, int(word_off[-1]), padded_slots(word_off, automaton, lex.silence_idx, sil_state), n_frames, len(frame_off) - 1, lexh.describe()),
             "recognised_words_rank0": int(woff[-1]),
+            "build": build_identity(),
         }
         if args.kernel == "prefilter":
             out.update(prefilter_report(args, prof, n_frames, D, S))
@@ -273,15 +274,19 @@ def gmm_roofline(args, prof, n_frames, D, S):
                   rate of the whole step is under "gmm_step").
     """
     launches = max(1, prof["gmm_launches"])
+    steps = max(1, args.steps)
     if args.kernel == "prefilter":
-        ms = prof["refine_ms"] / launches
+        # `n_frames` is what ONE STEP scores; a corpus whose score table needs several chunks takes several launches per step,
+        # so the step's flops go over the step's kernel time (= the launch-weighted mean: flops of a launch / its duration)
+        ms = prof["refine_ms"] / steps
         flops = 4.0 * D * S * n_frames
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         return {"kernel": "gmm_refine_kernel", "bound": "valu", "achieved": achieved, "peak": FP64_VALU_UNFUSED_PEAK,
                 "unit": "TFLOP/s", "frac": achieved / FP64_VALU_UNFUSED_PEAK, "traffic": pmc_traffic(args, n_frames, "gmm_refine_kernel"),
                 "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, KB units, separate rocprofv3 --pmc passes)",
                 "traffic_source": traffic_source(args, n_frames),
-                "launches": prof["gmm_launches"], "avg_launch_ms": ms,
+                "launches": prof["gmm_launches"], "chunks_per_step": prof["gmm_launches"] / steps, "ms_per_step": ms,
+                "avg_launch_ms": prof["refine_ms"] / launches, "frames_per_launch": n_frames * steps / launches,
                 "flops_per_frame": 4.0 * D * S, "dtype": "f64 unfused add/mul",
                 "note": "dominant kernel of the step; it is bound by the FP64 vector pipe (no MFMA, HBM traffic hidden), which "
                         "the hbm|mfma enum cannot name; the MFMA-bound prefilter kernel is under roofline_prefilter, the dense "
@@ -292,8 +297,8 @@ def gmm_roofline(args, prof, n_frames, D, S):
             "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
             "traffic": pmc_traffic(args, n_frames, "gmm_mfma_kernel") if args.kernel == "mfma" else None,
             "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, KB units, separate rocprofv3 --pmc passes)",
-            "launches": prof["gmm_launches"], "avg_launch_ms": prof["gmm_ms"] / launches,
-            "flops_per_frame": 4.0 * D * S * args.mix}
+            "launches": prof["gmm_launches"], "chunks_per_step": prof["gmm_launches"] / steps, "avg_launch_ms": prof["gmm_ms"] / launches,
+            "frames_per_launch": n_frames * steps / launches, "flops_per_frame": 4.0 * D * S * args.mix}
 
 
 def padded_slots(word_off, automaton, silence_idx, silence_state):
@@ -359,7 +364,8 @@ def search_report(args, prof, S, P, P_padded, n_frames, n_utts, network):
 
 def prefilter_report(args, prof, n_frames, D, S):
     launches = max(1, prof["gmm_launches"])
-    p_ms, g_ms = prof["prefilter_ms"] / launches, prof["gmm_ms"] / launches
+    steps = max(1, args.steps)
+    p_ms, g_ms = prof["prefilter_ms"] / steps, prof["gmm_ms"] / steps   # per STEP: the flops below are one step's (all chunks)
     k = 32 * ((2 * D + 3 + 31) // 32)
     cs = 1 if args.mix <= 32 else 2 if args.mix <= 64 else 4   # a mixture of more than 32 densities is cut into 2 or 4 chunks of 32 (pseudo-states)
     p_flops = 2.0 * k * (32 * 4 * ((S * cs + 3) // 4)) * n_frames  # executed: one fp16 product, K and (pseudo-)states padded
@@ -378,17 +384,26 @@ def prefilter_report(args, prof, n_frames, D, S):
         "roofline_prefilter": {"kernel": "gmm_prefilter16_kernel", "bound": "mfma", "achieved": p_flops / (p_ms * 1e-3) / 1e12,
                                "peak": F16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": p_flops / (p_ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS,
                                "frac_useful": p_useful / (p_ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS,
-                               "avg_launch_ms": p_ms, "dtype": "f16 x f16 -> f32", "includes": "feature transpose (0.04 ms)",
+                               "ms_per_step": p_ms, "avg_launch_ms": prof["prefilter_ms"] / launches, "chunks_per_step": prof["gmm_launches"] / steps,
+                               "dtype": "f16 x f16 -> f32", "includes": "feature transpose (0.04 ms)",
                                "mfma_pipe_busy": busy, "mfma_pipe_busy_source": traffic_source(args, n_frames),
                                "note": "frac counts the padded K = 96 that the MFMAs execute, frac_useful only K = 81; the matrix pipe is "
                                        "busy about half of the cycles (mfma_pipe_busy, from the PMC summary), the rest is the mask "
                                        "epilogue's vector issue (DESIGN 4.1)"},
-        "gmm_step": {"ms": g_ms, "dense_fp64_flops": dense, "dense_fp64_equiv_tflops": dense / (g_ms * 1e-3) / 1e12,
+        "gmm_step": {"ms": g_ms, "chunks_per_step": prof["gmm_launches"] / steps, "dense_fp64_flops": dense, "dense_fp64_equiv_tflops": dense / (g_ms * 1e-3) / 1e12,
                      "vs_fp64_mfma_peak": dense / (g_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS,
                      "densities_refined_per_pair": prof["refined_densities"] / max(1, prof["refined_pairs"]), "of": args.mix,
                      "note": "scores bit-identical to the reference; SURVEY 8(d)'s 4*D*C flops per frame are not executed in "
                              "FP64 any more, so the dense-equivalent rate exceeds the FP64 peak"},
     }
+
+
+def build_identity():
+    """Commit the library was built from (speechrecognition_amd/build.py records it: the GPU box has no .git) + the hash of
+    the device sources in this tree."""
+    from speechrecognition_amd import build as b
+    info = b.build_info()
+    return {"git_head": (info.get("git_head", "unknown") + ("+dirty" if info.get("dirty") else "")), "kernel_sources_sha16": kernel_sources_sha16()}
 
 
 def kernel_sources_sha16():
@@ -403,7 +418,7 @@ def kernel_sources_sha16():
     return h.hexdigest()[:16]
 
 
-PMC_SUMMARIES = {"prefilter": ("r3_prefilter_summary.json", "r2_prefilter_summary.json"), "mfma": ("r1_mfma_summary.json",)}
+PMC_SUMMARIES = {"prefilter": ("r4_prefilter_summary.json", "r3_prefilter_summary.json", "r2_prefilter_summary.json"), "mfma": ("r1_mfma_summary.json",)}
 
 
 def pmc_summary(args, n_frames):

@@ -93,7 +93,36 @@ def build(force=False, verbose=False):
             raise RuntimeError("link failed:\n" + r.stdout)
         with open(LIB + ".stamp", "w") as f:
             f.write(link_stamp)
+    write_build_info()
     return LIB
+
+
+BUILD_INFO = os.path.join(HERE, "BUILD_INFO.json")
+
+
+def write_build_info():
+    """Records the commit the tree was at (and whether it was dirty) next to the library: the GPU box gets the tree without
+    .git, and profile summaries / bench lines taken there must still name their commit (tools/summarize_profile.py, bench.py).
+    Only written where git answers; the file is git-ignored and travels with the snapshot like the .so."""
+    import json
+    try:
+        root = os.path.dirname(HERE)
+        head = subprocess.check_output(["git", "rev-parse", "--short=12", "HEAD"], cwd=root, text=True, stderr=subprocess.DEVNULL).strip()
+        dirty = bool(subprocess.check_output(["git", "status", "--porcelain", "--untracked-files=no"], cwd=root, text=True,
+                                             stderr=subprocess.DEVNULL).strip())
+    except (OSError, subprocess.CalledProcessError):
+        return
+    with open(BUILD_INFO, "w") as f:
+        json.dump({"git_head": head, "dirty": dirty}, f)
+
+
+def build_info():
+    import json
+    try:
+        with open(BUILD_INFO) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
 
 
 if __name__ == "__main__":

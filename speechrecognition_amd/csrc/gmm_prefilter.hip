@@ -424,8 +424,16 @@ static constexpr uint32_t kRingWave = 4 * kRingLists;         // u32 per wave: 1
 struct __attribute__((aligned(16))) RingEntry { uint32_t lf, mask; double score; };  // frame, candidates left, best score so far: one 16-byte store / load
 struct __attribute__((packed, aligned(4))) RowPiece { float v[4]; };  // 16 bytes of a feature row (rows are 4-byte aligned)
 
-template <int DT, int NS, int SPW>  // DT = compile-time feature dimension (0: run-time a.dim, features re-read from featsT)
+// CH = 32-slot chunks (pseudo-states) per state: 1, or 2 / 4 for mixtures of up to 64 / 128 densities.  A state's chunks are
+// consecutive panels of ONE workgroup (SPW is a multiple of CH and s0 of SPW), and the prefilter's candidate limit is relative
+// to the STATE's minimum, so for most pairs all but one of a state's masks are empty (93 % at 64 densities on the bench model):
+// the main pass evaluates ONE candidate per state -- the first of the state's first non-empty mask (round 4; until then it
+// evaluated one per pseudo-state and dropped the results of the empty ones: half of the FP64 work at 64 densities) -- and
+// everything else goes to the lists of the pseudo-state it belongs to.
+template <int DT, int NS, int SPW, int CH>  // DT = compile-time feature dimension (0: run-time a.dim, features re-read from featsT)
 __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) {
+  static_assert(CH == 1 || CH == 2 || CH == 4, "chunks per state");
+  static_assert(SPW % CH == 0 && (CH == 1 || SPW % 4 == 0), "a state's chunks live in one workgroup");
   extern __shared__ __attribute__((aligned(1024))) unsigned char panel_raw[];  // [SPW][state_bytes], 1 KB granular
   const uint32_t D = DT ? (uint32_t)DT : a.dim, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -576,7 +584,7 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
   uint64_t cnt1 = 0, cnt2 = 0;  // eight 8-bit counters each (wave-uniform): frames pending per state, level 1 / level 2
   const uint64_t f_wave = f_begin + (uint64_t)wave * 64;
   auto frame_of = [&](uint32_t lf) -> uint64_t { return f_wave + (uint64_t)(lf >> 6) * kRThreads + (lf & 63u); };
-  const uint32_t chunk_shift = a.chunks == 1 ? 0u : a.chunks == 2 ? 1u : 2u;
+  constexpr uint32_t chunk_shift = CH == 1 ? 0u : CH == 2 ? 1u : 2u;
 
   const uint32_t n_it = (uint32_t)((f_end - f_begin + kRThreads - 1) / kRThreads);
   for (uint32_t it = 0; it < n_it; it++) {
@@ -586,66 +594,88 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
     const uint32_t lf = it * 64u + (uint32_t)lane;
     load_x(f);
     // main pass: the first candidate of every state -- one evaluation per state in every lane, no divergence
-    double res[SPW];
-#pragma unroll
-    for (int h = 0; h < SPW / 4; h++) {
-      const uint4 v = reinterpret_cast<const uint4*>(a.mask)[(uint64_t)((s0 >> 2) + h) * a.n_frames + f];
-      const uint32_t mk[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int jj = 0; jj < 4; jj++) {
-        const int j = 4 * h + jj;
-        const uint32_t n = nd[j];
-        uint32_t mask = mk[jj];
-        mask &= n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);  // padding slots of the prefilter are not densities
-        res[j] = 1e10;  // min_score seed (Mixtures.cpp:699)
-        if (n) {        // wave-uniform (a state without densities has an empty mask and keeps the seed)
-          // (mask != 0 here: the prefilter keeps the approximate arg-min a candidate -- or everything, when the frame or the
-          // state is not a number -- and padding slots score +inf)
-          const double score = evaluate(panel_raw + (size_t)j * state_bytes + (uint32_t)__builtin_ctz(mask | 0x80000000u) * 8u);
-          res[j] = mask != 0 ? seeded_min(score) : res[j];
-          if (counting) n_eval += (uint32_t)__builtin_popcountll(__ballot(valid));  // (mask != 0, see above)
+    constexpr int RS = SPW / CH;  // whole states of this workgroup
+    double res[RS];
+    // appends the pairs of pseudo-state j whose lanes still hold candidates (`rest`) to j's level-1 list
+    auto append = [&](int j, bool more, uint32_t rest, double best) __attribute__((always_inline)) {
+      const uint64_t b = __ballot(more);
+      if (b) {  // wave-uniform
+        const uint32_t c1 = (uint32_t)(cnt1 >> (8 * j)) & 0xFFu;
+        const uint32_t pos = c1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+        if (more) {
+          ring[(uint32_t)j * kRingEntries + pos] = RingEntry{lf, rest, best};
         }
-        const bool more = valid && (mask & (mask - 1)) != 0;
-        const uint64_t b = __ballot(more);
-        if (b) {  // wave-uniform
-          const uint32_t c1 = (uint32_t)(cnt1 >> (8 * j)) & 0xFFu;
-          const uint32_t pos = c1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-          if (more) {
-            ring[(uint32_t)j * kRingEntries + pos] = RingEntry{lf, mask & (mask - 1), res[j]};
+        cnt1 += (uint64_t)__builtin_popcountll(b) << (8 * j);
+      }
+    };
+    if constexpr (CH == 1) {
+#pragma unroll
+      for (int h = 0; h < SPW / 4; h++) {
+        const uint4 v = reinterpret_cast<const uint4*>(a.mask)[(uint64_t)((s0 >> 2) + h) * a.n_frames + f];
+        const uint32_t mk[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int jj = 0; jj < 4; jj++) {
+          const int j = 4 * h + jj;
+          const uint32_t n = nd[j];
+          uint32_t mask = mk[jj];
+          mask &= n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);  // padding slots of the prefilter are not densities
+          res[j] = 1e10;  // min_score seed (Mixtures.cpp:699)
+          if (n) {        // wave-uniform (a state without densities has an empty mask and keeps the seed)
+            // (mask != 0 here: the prefilter keeps the approximate arg-min a candidate -- or everything, when the frame or the
+            // state is not a number -- and padding slots score +inf)
+            const double score = evaluate(panel_raw + (size_t)j * state_bytes + (uint32_t)__builtin_ctz(mask | 0x80000000u) * 8u);
+            res[j] = mask != 0 ? seeded_min(score) : res[j];
+            if (counting) n_eval += (uint32_t)__builtin_popcountll(__ballot(valid));  // (mask != 0, see above)
           }
-          cnt1 += (uint64_t)__builtin_popcountll(b) << (8 * j);
+          append(j, valid && (mask & (mask - 1)) != 0, mask & (mask - 1), res[j]);
+        }
+      }
+    } else {
+      uint32_t mk[SPW];
+#pragma unroll
+      for (int h = 0; h < SPW / 4; h++) {
+        const uint4 v = reinterpret_cast<const uint4*>(a.mask)[(uint64_t)((s0 >> 2) + h) * a.n_frames + f];
+        mk[4 * h] = v.x; mk[4 * h + 1] = v.y; mk[4 * h + 2] = v.z; mk[4 * h + 3] = v.w;
+      }
+#pragma unroll
+      for (int j = 0; j < SPW; j++) mk[j] &= nd[j] >= 32 ? 0xFFFFFFFFu : ((1u << nd[j]) - 1u);  // padding slots are not densities
+#pragma unroll
+      for (int r = 0; r < RS; r++) {
+        // the chunk that holds the lane's first candidate: the first non-empty mask of the state (min_score's scan order,
+        // Mixtures.cpp:700-708: densities ascending; the order does not matter for the result, see above)
+        uint32_t msel = mk[r * CH], off = 0;
+#pragma unroll
+        for (int c = 1; c < CH; c++) {
+          const bool empty = msel == 0;
+          msel = empty ? mk[r * CH + c] : msel;
+          off = empty ? (uint32_t)c * state_bytes : off;
+        }
+        res[r] = 1e10;  // min_score seed (Mixtures.cpp:699)
+        if (nd[r * CH]) {  // wave-uniform (a state without densities keeps the seed; chunk 0 fills first)
+          // lanes of one wave instruction now read up to CH panels: slot d of every panel of a state shares a bank pair
+          const double score = evaluate(panel_raw + (size_t)(r * CH) * state_bytes + off + (uint32_t)__builtin_ctz(msel | 0x80000000u) * 8u);
+          res[r] = msel != 0 ? seeded_min(score) : res[r];
+          if (counting) n_eval += (uint32_t)__builtin_popcountll(__ballot(valid));
+        }
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+          // what is left for the lists: the selected chunk without its first candidate; every later chunk in full (the
+          // earlier ones are empty).  The batches take the best score so far from the table (shared by the state's chunks).
+          const bool is_sel = off == (uint32_t)c * state_bytes;
+          const uint32_t rest = is_sel ? msel & (msel - 1) : mk[r * CH + c];
+          if (nd[r * CH + c]) append(r * CH + c, valid && rest != 0, rest, res[r]);
         }
       }
     }
-    // a mixture of more than 32 densities spans `chunks` consecutive pseudo-states: fold their minima (NaN never
-    // wins, as in the reference's scan)
     if (valid) {
-      if (a.chunks == 1) {
-        double* o = a.out + f * a.ld + s0;
-        if (ns == SPW) {  // ld is a multiple of 8: 64-byte (32-byte for SPW = 4) aligned pieces
+      double* o = a.out + f * a.ld + s0 / CH;
+      if (ns == SPW && RS >= 2) {  // ld is a multiple of 8 and s0 / CH one of RS: 16-byte aligned pairs
 #pragma unroll
-          for (int j = 0; j < SPW; j += 2) *reinterpret_cast<double2*>(o + j) = make_double2(res[j], res[j + 1]);
-        } else {
+        for (int r = 0; r < RS; r += 2) *reinterpret_cast<double2*>(o + r) = make_double2(res[r], res[r + 1]);
+      } else {
 #pragma unroll
-          for (int j = 0; j < SPW; j++)
-            if ((uint32_t)j < ns) o[j] = res[j];
-        }
-      } else if (a.chunks == 2) {
-        double* o = a.out + f * a.ld + s0 / 2;
-#pragma unroll
-        for (int j = 0; j < SPW; j += 2) {
-          const double m = res[j + 1] < res[j] ? res[j + 1] : res[j];
-          if ((uint32_t)j < ns) o[j / 2] = m;
-        }
-      } else {  // 4
-        double* o = a.out + f * a.ld + s0 / 4;
-#pragma unroll
-        for (int j = 0; j < SPW; j += 4) {
-          double m = res[j + 1] < res[j] ? res[j + 1] : res[j];
-          m = res[j + 2] < m ? res[j + 2] : m;
-          m = res[j + 3] < m ? res[j + 3] : m;
-          if ((uint32_t)j < ns) o[j / 4] = m;
-        }
+        for (int r = 0; r < RS; r++)
+          if ((uint32_t)(r * CH) < ns) o[r] = res[r];
       }
     }
     // ---- work off the lists: every list is kept below 64 pending frames (one more iteration's appends must fit);
@@ -771,7 +801,7 @@ size_t gmm_refine_ring_words(const GmmRefineArgs& a) {
   return (size_t)g * sp * kRWaves * kRingWave;
 }
 
-template <int NS, int SPW>
+template <int NS, int SPW, int CH = 1>
 static hipError_t launch_refine_ns(const GmmRefineArgs& a0, hipStream_t stream) {
   GmmRefineArgs a = a0;
   const size_t state_bytes = (size_t)(2 * a.dim + 2) * NS * 8;
@@ -787,9 +817,9 @@ static hipError_t launch_refine_ns(const GmmRefineArgs& a0, hipStream_t stream) 
     return hipGetLastError();
   };
   switch (a.dim) {
-    case 39: return go(gmm_refine_kernel<39, NS, SPW>);
-    case 25: return go(gmm_refine_kernel<25, NS, SPW>);
-    default: return go(gmm_refine_kernel<0, NS, SPW>);
+    case 39: return go(gmm_refine_kernel<39, NS, SPW, CH>);
+    case 25: return go(gmm_refine_kernel<25, NS, SPW, CH>);
+    default: return go(gmm_refine_kernel<0, NS, SPW, CH>);
   }
 }
 
@@ -797,10 +827,15 @@ hipError_t launch_gmm_refine(const GmmRefineArgs& a, hipStream_t stream) {
   if (a.n_frames == 0) return hipSuccess;
   if (!a.ring || (uint64_t)a.dim * a.n_frames_ld * 4u >= (1ull << 32)) return hipErrorInvalidValue;  // (buffer offsets are 32 bit)
   const bool eight = refine_spw(a) == 8;
+  if (a.chunks != 1 && (a.n_slots != 32 || (a.chunks != 2 && a.chunks != 4))) return hipErrorInvalidValue;
   switch (a.n_slots) {
     case 8: return launch_refine_ns<8, 8>(a, stream);
     case 16: return launch_refine_ns<16, 8>(a, stream);
-    case 32: return eight ? launch_refine_ns<32, 8>(a, stream) : launch_refine_ns<32, 4>(a, stream);
+    case 32:
+      // (a mixture of more than 32 densities always has 32-slot panels)
+      if (a.chunks == 2) return eight ? launch_refine_ns<32, 8, 2>(a, stream) : launch_refine_ns<32, 4, 2>(a, stream);
+      if (a.chunks == 4) return eight ? launch_refine_ns<32, 8, 4>(a, stream) : launch_refine_ns<32, 4, 4>(a, stream);
+      return eight ? launch_refine_ns<32, 8>(a, stream) : launch_refine_ns<32, 4>(a, stream);
     default: return hipErrorInvalidValue;
   }
 }

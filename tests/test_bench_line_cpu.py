@@ -50,3 +50,36 @@ def test_decode_geometry_report():
     assert bench.decode_geometry(4096, 1000) == "1024, 4"
     assert bench.decode_geometry(1216, 1) == "1024, 2"
     assert bench.decode_geometry(9000, 10) is None
+
+
+def test_roofline_fractions_do_not_depend_on_the_number_of_score_chunks():
+    """VERDICT r3 #1 / ADVICE r3: a corpus whose score table is cut into chunks takes several scoring launches per step; the
+    step's flops must go over the step's kernel time, not over ONE launch's (profiles/r3_bench_cfg4_one_gpu.json showed the
+    refinement at 0.62 of its peak and the prefilter at 0.77 that way, twice their real figures)."""
+    D, S, frames = 39, 4000, 300000
+
+    def prof(launches_per_step, steps):
+        # the same kernels at the same rate: the work of a step takes the same time however it is cut
+        return {"gmm_launches": launches_per_step * steps, "refine_ms": 14.0 * steps, "prefilter_ms": 7.0 * steps, "gmm_ms": 21.0 * steps,
+                "gmm_flops": 4.0 * D * S * 32 * frames * steps, "refined_densities": 11, "refined_pairs": 10,
+                "search_ms": 2.0 * steps, "search_bytes": 48e3 * frames * steps}
+
+    lines = []
+    for lps, steps in ((1, 3), (2, 3), (3, 5)):
+        a = types.SimpleNamespace(kernel="prefilter", words=1333, mix=32, steps=steps)
+        r = bench.gmm_roofline(a, prof(lps, steps), frames, D, S)
+        p = bench.prefilter_report(a, prof(lps, steps), frames, D, S)
+        assert r["chunks_per_step"] == lps and abs(r["avg_launch_ms"] - 14.0 / lps) < 1e-12 and abs(r["ms_per_step"] - 14.0) < 1e-12
+        assert r["frames_per_launch"] == frames / lps
+        lines.append((r["frac"], p["roofline_prefilter"]["frac"], p["roofline_prefilter"]["frac_useful"], p["gmm_step"]["ms"],
+                      p["gmm_step"]["dense_fp64_equiv_tflops"]))
+    for other in lines[1:]:
+        for x, y in zip(lines[0], other):
+            assert abs(x - y) <= 1e-12 * abs(x)
+    # the figures themselves: one exact density per (frame, state) in 14 ms; K = 96 executed on the matrix cores in 7 ms
+    assert abs(lines[0][0] - 4.0 * D * S * frames / 14e-3 / 1e12 / bench.FP64_VALU_UNFUSED_PEAK) < 1e-12
+    assert abs(lines[0][1] - 2.0 * 96 * 128000 * frames / 7e-3 / 1e12 / bench.F16_MFMA_PEAK_TFLOPS) < 1e-12
+    # the dense kernels' line: gmm_flops and gmm_ms are both sums over the launches
+    a = types.SimpleNamespace(kernel="mfma", words=1333, mix=32, steps=3)
+    one, two = bench.gmm_roofline(a, prof(1, 3), frames, D, S), bench.gmm_roofline(a, prof(2, 3), frames, D, S)
+    assert one["frac"] == two["frac"] and two["chunks_per_step"] == 2

@@ -36,7 +36,12 @@ try:
     out["git_head"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True, stderr=subprocess.DEVNULL,
                                               cwd=os.path.dirname(os.path.abspath(__file__))).strip()
 except (OSError, subprocess.CalledProcessError):
-    pass  # the GPU box has no .git: the commit is added when the summary is copied into profiles/
+    # the GPU box has no .git: the build recorded the commit next to the library (speechrecognition_amd/build.py, BUILD_INFO.json)
+    try:
+        info = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "speechrecognition_amd", "BUILD_INFO.json")))
+        out["git_head"] = info["git_head"] + ("+dirty" if info.get("dirty") else "")
+    except (OSError, ValueError, KeyError):
+        pass
 try:
     out["bench_line_under_profiler"] = json.loads(open(os.path.join(root, "bench_under_profiler.json")).read())
     cfg = out["bench_line_under_profiler"]["config"]
