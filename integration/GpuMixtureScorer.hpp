@@ -12,6 +12,8 @@
 #ifndef __GPU_MIXTURE_SCORER_HPP__
 #define __GPU_MIXTURE_SCORER_HPP__
 
+#include <map>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -27,7 +29,7 @@ public:
   // same arguments as MixtureModel's constructor in recognize mode (Mixtures.cpp:156-174); pooling is
   // MixtureModel::VarianceModel cast to int
   GpuMixtureScorer(std::string const& mixture_path, size_t dimension, int pooling, bool max_approx, int device = 0)
-                  : dimension_(dimension), model_(NULL), start_(NULL) {
+                  : dimension_(dimension), model_(NULL) {
     if (sr_model_load_mixset(mixture_path.c_str(), dimension, pooling, max_approx, device, &model_) != SR_OK) {
       throw std::runtime_error(sr_last_error());
     }
@@ -36,30 +38,53 @@ public:
   }
   virtual ~GpuMixtureScorer() { sr_model_destroy(model_); }
 
-  // NOTE: like NeuralNetwork::prepare_sequence this keeps per-sequence state, so it is not safe under the
-  // `#pragma omp parallel for` of Recognizer::recognize (Recognizer.cpp:46); use gpu_recognize() for corpora.
+  // Safe under the `#pragma omp parallel for` of Recognizer::recognize (Recognizer.cpp:46), which calls
+  // prepare_sequence + score for a different segment on every thread through ONE scorer object
+  // (Recognizer.cpp:104): the per-sequence table lives in a per-thread slot (NeuralNetwork keeps its
+  // table in the object and is not safe there), and the device call is serialised -- srgpu.h: a handle
+  // is used by one host thread at a time.  The threads then overlap one segment's device scoring with
+  // the others' host-side search; gpu_recognize() below is still the faster route for whole corpora.
   virtual void prepare_sequence(FeatureIter const& start, FeatureIter const& end) {
+    Sequence& seq = sequence();
     const size_t n_frames = end - start;
-    start_ = *start;
-    table_.resize(n_frames * num_states_);
-    if (sr_score_frames(model_, *start, n_frames, SR_GMM_PREFILTER, table_.data()) != SR_OK) {
+    seq.start = *start;
+    seq.table.resize(n_frames * num_states_);
+    std::lock_guard<std::mutex> lock(device_mutex_);
+    if (sr_score_frames(model_, *start, n_frames, SR_GMM_PREFILTER, seq.table.data()) != SR_OK) {
       throw std::runtime_error(sr_last_error());
     }
   }
 
   virtual double score(FeatureIter const& iter, StateIdx state_idx) const {
-    const size_t frame = (*iter - start_) / dimension_;  // as NeuralNetwork::score recovers it (NeuralNetwork.cpp:196-198)
-    return table_[frame * num_states_ + state_idx];
+    Sequence const& seq = sequence();
+    const size_t frame = (*iter - seq.start) / dimension_;  // as NeuralNetwork::score recovers it (NeuralNetwork.cpp:196-198)
+    return seq.table[frame * num_states_ + state_idx];
   }
 
   sr_model* handle() const { return model_; }
 
 private:
-  size_t              dimension_;
-  sr_model*           model_;
-  uint32_t            num_states_;
-  const float*        start_;
-  std::vector<double> table_;
+  struct Sequence {
+    const float*        start;
+    std::vector<double> table;
+    Sequence() : start(NULL) {}
+  };
+  // the calling thread's slot for THIS scorer (a thread may drive several scorers; the last one used is cached)
+  Sequence& sequence() const {
+    static thread_local std::map<const GpuMixtureScorer*, Sequence> slots;
+    static thread_local const GpuMixtureScorer* last_owner = NULL;
+    static thread_local Sequence*               last       = NULL;
+    if (last_owner != this) {
+      last       = &slots[this];
+      last_owner = this;
+    }
+    return *last;
+  }
+
+  size_t             dimension_;
+  sr_model*          model_;
+  uint32_t           num_states_;
+  mutable std::mutex device_mutex_;
 };
 
 // Whole-corpus recognition on the device: what Recognizer::recognize's loop body computes per segment

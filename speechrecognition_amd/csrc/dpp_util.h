@@ -28,15 +28,22 @@ __device__ inline double dmin(double a, double b) {
   return r;
 }
 __device__ inline uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
-// LDS ds_min_f64, no return value (the cell is read after the workgroup barrier)
-__device__ inline void atomic_min_f64_lds(double* cell, double v) {
-  asm volatile("ds_min_f64 %0, %1" : : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)cell), "v"(v) : "memory");
+// LDS ds_min_f64 without a return value, then the wait that has to stand between such an atomic and the barrier behind which
+// the cell is read -- ONE asm statement, so that no call site can have the first without the second.  The compiler does not see a
+// DS instruction inside an asm, so its own "s_waitcnt lgkmcnt(0)" before s_barrier is there only when some OTHER LDS access
+// happens to be pending; without the wait a wave can pass the barrier while its minimum is still queued, and the waves that read
+// the cell first see different minima (round 3: one traceback entry in ~1e5 wrong, run to run, once a second copy of the frame
+// loop was compiled without it; until round 4 the wait was a separate helper every call site had to remember).
+// tests/test_isa_cpu.py checks the binary: every ds_min_f64 is followed by s_waitcnt lgkmcnt(0) before the next s_barrier.
+__device__ inline uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
+__device__ inline void publish_min_f64_lds(double* cell, double v) {
+  asm volatile("ds_min_f64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : : "v"(lds_addr(cell)), "v"(v) : "memory");
 }
-// ... and the wait that has to stand between those atomics and the barrier: the compiler does not see the DS instruction inside
-// the asm, so its own "s_waitcnt lgkmcnt(0)" before s_barrier is there only when some OTHER LDS access happens to be pending --
-// without it a wave can pass the barrier while its minimum is still queued, and the waves that read the cell first see different
-// minima (round 3: one traceback entry in ~1e5 wrong, run to run, once a second copy of the frame loop was compiled without it).
-__device__ inline void lds_atomics_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// two cells, both atomics in flight together, one wait
+__device__ inline void publish_min2_f64_lds(double* cell0, double v0, double* cell1, double v1) {
+  asm volatile("ds_min_f64 %0, %1\n\tds_min_f64 %2, %3\n\ts_waitcnt lgkmcnt(0)"
+               : : "v"(lds_addr(cell0)), "v"(v0), "v"(lds_addr(cell1)), "v"(v1) : "memory");
+}
 // full-wave minimum, returned to every lane
 __device__ inline double wave_min_dpp(double v) {
   v = dmin(v, dpp_d<0xB1, 0xF>(v));    // quad_perm [1,0,3,2]

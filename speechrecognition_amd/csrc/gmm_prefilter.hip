@@ -584,7 +584,11 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
   uint64_t cnt1 = 0, cnt2 = 0;  // eight 8-bit counters each (wave-uniform): frames pending per state, level 1 / level 2
   const uint64_t f_wave = f_begin + (uint64_t)wave * 64;
   auto frame_of = [&](uint32_t lf) -> uint64_t { return f_wave + (uint64_t)(lf >> 6) * kRThreads + (lf & 63u); };
-  constexpr uint32_t chunk_shift = CH == 1 ? 0u : CH == 2 ? 1u : 2u;
+  // (CH == 1 reads the shift from the kernel argument although it is 0 there, and keeps the run-time branches of the round-3
+  // kernel below: with the shift folded to a constant the compiler schedules the SAME instruction mix 1.0 ms slower on
+  // configs[2] -- 16.0 against 15.0 ms, A/B on one box, gpurun_out/r4_ab_refine_cfg3.txt; profiles/r3_refine_closed.txt has
+  // seen that before: "the present order is a local optimum somebody found")
+  const uint32_t chunk_shift = CH == 1 ? (a.chunks == 1 ? 0u : a.chunks == 2 ? 1u : 2u) : CH == 2 ? 1u : 2u;
 
   const uint32_t n_it = (uint32_t)((f_end - f_begin + kRThreads - 1) / kRThreads);
   for (uint32_t it = 0; it < n_it; it++) {
@@ -596,18 +600,6 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
     // main pass: the first candidate of every state -- one evaluation per state in every lane, no divergence
     constexpr int RS = SPW / CH;  // whole states of this workgroup
     double res[RS];
-    // appends the pairs of pseudo-state j whose lanes still hold candidates (`rest`) to j's level-1 list
-    auto append = [&](int j, bool more, uint32_t rest, double best) __attribute__((always_inline)) {
-      const uint64_t b = __ballot(more);
-      if (b) {  // wave-uniform
-        const uint32_t c1 = (uint32_t)(cnt1 >> (8 * j)) & 0xFFu;
-        const uint32_t pos = c1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-        if (more) {
-          ring[(uint32_t)j * kRingEntries + pos] = RingEntry{lf, rest, best};
-        }
-        cnt1 += (uint64_t)__builtin_popcountll(b) << (8 * j);
-      }
-    };
     if constexpr (CH == 1) {
 #pragma unroll
       for (int h = 0; h < SPW / 4; h++) {
@@ -627,10 +619,62 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
             res[j] = mask != 0 ? seeded_min(score) : res[j];
             if (counting) n_eval += (uint32_t)__builtin_popcountll(__ballot(valid));  // (mask != 0, see above)
           }
-          append(j, valid && (mask & (mask - 1)) != 0, mask & (mask - 1), res[j]);
+          const bool more = valid && (mask & (mask - 1)) != 0;
+          const uint64_t b = __ballot(more);
+          if (b) {  // wave-uniform
+            const uint32_t c1 = (uint32_t)(cnt1 >> (8 * j)) & 0xFFu;
+            const uint32_t pos = c1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+            if (more) {
+              ring[(uint32_t)j * kRingEntries + pos] = RingEntry{lf, mask & (mask - 1), res[j]};
+            }
+            cnt1 += (uint64_t)__builtin_popcountll(b) << (8 * j);
+          }
+        }
+      }
+      // (the chunks == 2 / 4 branches are never taken in this instantiation -- the launcher sends such models to CH = 2 / 4 --
+      // but they are part of the schedule, see chunk_shift above)
+      if (valid) {
+        if (a.chunks == 1) {
+          double* o = a.out + f * a.ld + s0;
+          if (ns == SPW) {  // ld is a multiple of 8: 64-byte (32-byte for SPW = 4) aligned pieces
+#pragma unroll
+            for (int j = 0; j < SPW; j += 2) *reinterpret_cast<double2*>(o + j) = make_double2(res[j], res[j + 1]);
+          } else {
+#pragma unroll
+            for (int j = 0; j < SPW; j++)
+              if ((uint32_t)j < ns) o[j] = res[j];
+          }
+        } else if (a.chunks == 2) {
+          double* o = a.out + f * a.ld + s0 / 2;
+#pragma unroll
+          for (int j = 0; j < SPW; j += 2) {
+            const double m = res[j + 1] < res[j] ? res[j + 1] : res[j];
+            if ((uint32_t)j < ns) o[j / 2] = m;
+          }
+        } else {  // 4
+          double* o = a.out + f * a.ld + s0 / 4;
+#pragma unroll
+          for (int j = 0; j < SPW; j += 4) {
+            double m = res[j + 1] < res[j] ? res[j + 1] : res[j];
+            m = res[j + 2] < m ? res[j + 2] : m;
+            m = res[j + 3] < m ? res[j + 3] : m;
+            if ((uint32_t)j < ns) o[j / 4] = m;
+          }
         }
       }
     } else {
+      // appends the pairs of pseudo-state j whose lanes still hold candidates (`rest`) to j's level-1 list
+      auto append = [&](int j, bool more, uint32_t rest, double best) __attribute__((always_inline)) {
+        const uint64_t b = __ballot(more);
+        if (b) {  // wave-uniform
+          const uint32_t c1 = (uint32_t)(cnt1 >> (8 * j)) & 0xFFu;
+          const uint32_t pos = c1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+          if (more) {
+            ring[(uint32_t)j * kRingEntries + pos] = RingEntry{lf, rest, best};
+          }
+          cnt1 += (uint64_t)__builtin_popcountll(b) << (8 * j);
+        }
+      };
       uint32_t mk[SPW];
 #pragma unroll
       for (int h = 0; h < SPW / 4; h++) {
@@ -666,16 +710,16 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
           if (nd[r * CH + c]) append(r * CH + c, valid && rest != 0, rest, res[r]);
         }
       }
-    }
-    if (valid) {
-      double* o = a.out + f * a.ld + s0 / CH;
-      if (ns == SPW && RS >= 2) {  // ld is a multiple of 8 and s0 / CH one of RS: 16-byte aligned pairs
+      if (valid) {
+        double* o = a.out + f * a.ld + s0 / CH;
+        if (ns == SPW && RS >= 2) {  // ld is a multiple of 8 and s0 / CH one of RS: 16-byte aligned pairs
 #pragma unroll
-        for (int r = 0; r < RS; r += 2) *reinterpret_cast<double2*>(o + r) = make_double2(res[r], res[r + 1]);
-      } else {
+          for (int r = 0; r + 1 < RS; r += 2) *reinterpret_cast<double2*>(o + r) = make_double2(res[r], res[r + 1]);
+        } else {
 #pragma unroll
-        for (int r = 0; r < RS; r++)
-          if ((uint32_t)(r * CH) < ns) o[r] = res[r];
+          for (int r = 0; r < RS; r++)
+            if ((uint32_t)(r * CH) < ns) o[r] = res[r];
+        }
       }
     }
     // ---- work off the lists: every list is kept below 64 pending frames (one more iteration's appends must fit);

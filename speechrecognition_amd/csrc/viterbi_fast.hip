@@ -337,12 +337,12 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
 
     // ---- B: block minima through LDS ds_min_f64 cells, fed by one lane per row ------------------------------------
     my_best = row_min_dpp(my_best);
-    if ((lane & 15u) == 0) atomic_min_f64_lds(&c_best[par], my_best);
-    if (wave_has_we) {
+    if (wave_has_we) {  // (wave-uniform; the atomics and their wait are one statement, dpp_util.h)
       my_we = row_min_dpp(my_we);
-      if ((lane & 15u) == 0) atomic_min_f64_lds(&c_we[par], my_we);
+      if ((lane & 15u) == 0) publish_min2_f64_lds(&c_best[par], my_best, &c_we[par], my_we);
+    } else if ((lane & 15u) == 0) {
+      publish_min_f64_lds(&c_best[par], my_best);
     }
-    lds_atomics_done();
     __syncthreads();
 
     // ---- C: prune, publish the word-end minimum --------------------------------------------------------------------

@@ -273,8 +273,7 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
     // ---- B: block minima through LDS ds_min_f64 cells, fed by one lane per row of 16 ---------------------------------------
     my_best = row_min_dpp(my_best);
     my_we = row_min_dpp(my_we);
-    if ((lane & 15u) == 0) { atomic_min_f64_lds(&c_best[r], my_best); atomic_min_f64_lds(&c_we[r], my_we); }
-    lds_atomics_done();
+    if ((lane & 15u) == 0) publish_min2_f64_lds(&c_best[r], my_best, &c_we[r], my_we);  // (atomics + their wait: dpp_util.h)
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of the next row have landed; the barrier publishes them
     __syncthreads();
 
