@@ -53,7 +53,10 @@ def parse():
                          "cfg5 = configs[4] (8000 states x 64, bigram search)")
     ap.add_argument("--mix", type=int, default=32)
     ap.add_argument("--beam", type=float, default=200.0)
-    ap.add_argument("--kernel", choices=["mfma", "exact", "prefilter"], default="prefilter",
+    ap.add_argument("--sum-mode", action="store_true",
+                    help="score with max-approx false: -log sum_d exp(-score_d) per state (Mixtures.cpp:719-728) instead of the minimum; "
+                         "the library's default kernel for such a model is the dense FP64-MFMA one (SR_GMM_DEFAULT)")
+    ap.add_argument("--kernel", choices=["mfma", "exact", "prefilter", "default"], default="prefilter",
                     help="GMM scoring path: prefilter (fp16 MFMA candidate pass + exact FP64 refinement, bit-exact scores), "
                          "mfma (dense FP64 MFMA, ~1e-15), exact (dense FP64 VALU, bit-exact)")
     ap.add_argument("--decoder", choices=["zerogram", "bigram"], default="zerogram",
@@ -67,6 +70,8 @@ def parse():
     args = ap.parse_args()
     if args.config == "cfg4":
         args.total_utts = 10000
+    if args.sum_mode and args.kernel == "prefilter":
+        args.kernel = "default"
     if args.config == "cfg5":
         args.words, args.extra_states_last, args.mix, args.decoder = 2666, 1, 64, "bigram"
     return args
@@ -134,9 +139,13 @@ def main():
     del all_feats
     n_frames = int(frame_off[-1])
     word_off, automaton, sil_state = lex.flatten()
-    kernel = {"mfma": capi.GMM_MFMA, "exact": capi.GMM_EXACT, "prefilter": capi.GMM_PREFILTER}[args.kernel]
+    kernel = {"mfma": capi.GMM_MFMA, "exact": capi.GMM_EXACT, "prefilter": capi.GMM_PREFILTER, "default": capi.GMM_DEFAULT}[args.kernel]
+    if args.kernel == "default":  # what SR_GMM_DEFAULT resolves to for this model (srgpu.h): the report names the kernel that ran
+        args.kernel = "mfma" if args.sum_mode else "prefilter"
+    elif args.sum_mode and args.kernel == "prefilter":
+        args.kernel = "exact"     # SR_GMM_PREFILTER on a sum-mode model is scored by the exact kernel (same bits as SR_GMM_EXACT)
 
-    model = capi.Model.from_mixset(mixset_path, D, capi.POOL_NONE, True, device=device)
+    model = capi.Model.from_mixset(mixset_path, D, capi.POOL_NONE, not args.sum_mode, device=device)
     lexh = model.lexicon(word_off, automaton, lex.silence_idx, tdp, sil_state)
     corpus = model.upload(feats, frame_off)  # inputs resident in HBM before timing starts
 
@@ -178,7 +187,7 @@ def main():
     # north_star's "MFMA utilisation on the GMM step": the headline path no longer executes the dense FP64 contraction, so the
     # dense FP64-MFMA kernel (same scores to 1e-9) is timed once beside it, outside the timed region, for that figure
     dense_mfma = None
-    if rank == 0 and world == 1 and args.kernel == "prefilter" and bg is None and not args.no_dense_mfma:
+    if rank == 0 and world == 1 and args.kernel == "prefilter" and bg is None and not args.no_dense_mfma and not args.sum_mode:
         corpus.recognize(lexh, args.beam, wp, capi.GMM_MFMA)  # builds the packing
         model.profile(True)
         torch.cuda.synchronize()
@@ -221,6 +230,8 @@ def main():
                 "states": S, "mixtures": args.mix, "feat_dim": D, "utterances_total": total_utts,
                 "utterances_rank0": len(frame_off) - 1, "frames_rank0": n_frames, "words": lex.n_words,
                 "trellis_positions": int(word_off[-1]), "gmm_kernel": args.kernel,
+                "mixture_score": "sum: -log sum exp(-score_d) (max-approx false, Mixtures.cpp:719-728; device exp/log: 1e-12 relative)" if args.sum_mode
+                                 else "max-approx: min over the densities (Mixtures.cpp:696-713), bit-exact",
                 "parallelism": f"utterance-shard x{world} (greedy LPT by frames), no collective",
                 "shard_imbalance": max(shard_frames) / (sum(shard_frames) / world),  # heaviest shard / mean: what strong scaling can lose
             },
@@ -493,7 +504,7 @@ def cpu_baseline(args, mixset_path, lex, tdp, wp, feats, frame_off, gpu_words, g
 
     cores = usable_cores()
     model_name, host_cpus = cpu_model()
-    orc = pyoracle.Oracle(mixset_path, 39, lex, tdp=tdp, am_threshold=args.beam, word_penalty=wp)
+    orc = pyoracle.Oracle(mixset_path, 39, lex, tdp=tdp, am_threshold=args.beam, word_penalty=wp, max_approx=not args.sum_mode)
     lens = np.diff(frame_off.astype(np.int64))
     u0 = int(np.argmin(lens))
     f0 = feats[int(frame_off[u0]):int(frame_off[u0 + 1])]

@@ -120,7 +120,7 @@ class MixtureModel : public FeatureScorer {
   // MixtureModel(config, dimension, num_mixtures, var_model, max_approx) with action "recognize" and
   // "load-mixtures-from" = path (Mixtures.cpp:156-174)
   MixtureModel(std::string const& load_mixtures_from, size_t dimension, VarianceModel var_model, bool max_approx,
-               int device = 0, int gmm_kernel = SR_GMM_PREFILTER)
+               int device = 0, int gmm_kernel = SR_GMM_DEFAULT)
       : dimension(dimension), var_model(var_model), gmm_kernel(gmm_kernel), path_(load_mixtures_from), max_approx_(max_approx),
         device_(device) {
     check(sr_model_load_mixset(load_mixtures_from.c_str(), (uint32_t)dimension, (int)var_model, max_approx ? 1 : 0, device, &h_));

@@ -51,6 +51,12 @@ extern "C" {
                                minimum, FP64 replays only those.  Max-approx models with <= 128 densities per mixture and
                                dim <= 46; any other model is scored by SR_GMM_EXACT's kernel instead (same bits). */
 
+#define SR_GMM_DEFAULT 3  /* what a drop-in caller wants: the fastest kernel that reproduces MixtureModel::score for THIS model --
+                             SR_GMM_PREFILTER (bit-exact) for max-approx models; for sum scoring (max-approx false,
+                             Mixtures.cpp:719-728) the FP64-MFMA kernel with its fused -log sum exp: device exp / log put every
+                             sum-mode kernel 1e-12 from the reference's libm either way, and the dense direct form is 3x slower.
+                             The aligner / path-score entry points score only the states they need with the bit-exact kernel. */
+
 typedef struct sr_model sr_model;     /* replaces MixtureModel as a FeatureScorer (Mixtures.hpp:18, FeatureScorer.hpp:12-16) */
 typedef struct sr_corpus sr_corpus;   /* replaces Corpus' feature store (Corpus.hpp:79-84, Corpus.cpp:141-144) */
 typedef struct sr_lexicon sr_lexicon; /* replaces Lexicon + TdpModel as search network (Lexicon.hpp:16-33, TdpModel.hpp:13-29) */

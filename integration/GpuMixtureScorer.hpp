@@ -50,7 +50,7 @@ public:
     seq.start = *start;
     seq.table.resize(n_frames * num_states_);
     std::lock_guard<std::mutex> lock(device_mutex_);
-    if (sr_score_frames(model_, *start, n_frames, SR_GMM_PREFILTER, seq.table.data()) != SR_OK) {
+    if (sr_score_frames(model_, *start, n_frames, SR_GMM_DEFAULT, seq.table.data()) != SR_OK) {
       throw std::runtime_error(sr_last_error());
     }
   }
@@ -114,7 +114,7 @@ inline void gpu_recognize(GpuMixtureScorer const& scorer, Lexicon const& lexicon
   }
   std::vector<uint32_t> words(frame_off[corpus_size] + 1);
   std::vector<uint64_t> out_off(corpus_size + 1);
-  sr_search_params p = {am_threshold, word_penalty, SR_GMM_PREFILTER, 0};
+  sr_search_params p = {am_threshold, word_penalty, SR_GMM_DEFAULT, 0};
   const int rc = sr_recognize_batch(scorer.handle(), net, &p, *corpus.get_feature_sequence(0).first, frame_off.data(),
                                     corpus_size, words.data(), out_off.data());
   sr_lexicon_destroy(net);
@@ -165,7 +165,7 @@ inline void gpu_recognize(std::vector<GpuMixtureScorer*> const& scorers, Lexicon
   }
   std::vector<uint32_t> words(frame_off[corpus_size] + 1);
   std::vector<uint64_t> out_off(corpus_size + 1);
-  sr_search_params p = {am_threshold, word_penalty, SR_GMM_PREFILTER, 0};
+  sr_search_params p = {am_threshold, word_penalty, SR_GMM_DEFAULT, 0};
   if (sr_recognize_batch_multi(models.data(), nets.data(), models.size(), &p, *corpus.get_feature_sequence(0).first,
                                frame_off.data(), corpus_size, words.data(), out_off.data(), NULL) != SR_OK) {
     throw std::runtime_error(sr_last_error());

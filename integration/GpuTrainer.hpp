@@ -71,9 +71,9 @@ public:
     std::vector<double> cost(n + 1u);
     const int rc = alignment_pruning_
         ? sr_align_corpus_pruned(scorer_.handle(), corpus_, automata.data(), aut_off.data(), tdp_, silence_state_,
-                                 pruning_threshold_, SR_GMM_PREFILTER, states.data(), cost.data())
+                                 pruning_threshold_, SR_GMM_DEFAULT, states.data(), cost.data())
         : sr_align_corpus(scorer_.handle(), corpus_, automata.data(), aut_off.data(), tdp_, silence_state_,
-                          SR_GMM_PREFILTER, states.data(), cost.data());
+                          SR_GMM_DEFAULT, states.data(), cost.data());
     check(rc);
     alignment.resize(frames * num_max_aligns_);
     for (size_t t = 0ul; t < frames; t++) {
@@ -90,7 +90,7 @@ public:
     std::vector<uint16_t> states(frames + 1u);
     for (size_t t = 0ul; t < frames; t++) states[t] = alignment[t * num_max_aligns_].state;
     std::vector<double> per_frame(frames + 1u);
-    check(sr_path_scores_corpus(scorer_.handle(), corpus_, states.data(), SR_GMM_PREFILTER, per_frame.data()));
+    check(sr_path_scores_corpus(scorer_.handle(), corpus_, states.data(), SR_GMM_DEFAULT, per_frame.data()));
     double total_score = 0.0;
     for (size_t t = 0ul; t < frames; t++) total_score += per_frame[t];
     return total_score / frames;

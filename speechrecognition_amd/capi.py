@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # SRGPU_LIB: a differently tuned build of the same library (tools/build_variant.py), for A/B timing only
 LIB_PATH = os.environ.get("SRGPU_LIB") or os.path.join(HERE, "libsrgpu.so")
 
-GMM_MFMA, GMM_EXACT, GMM_PREFILTER = 0, 1, 2
+GMM_MFMA, GMM_EXACT, GMM_PREFILTER, GMM_DEFAULT = 0, 1, 2, 3
 POOL_GLOBAL, POOL_MIXTURE, POOL_NONE = 0, 1, 2
 SEARCH_GENERAL_KERNEL = 1
 SEARCH_SLOT_KERNEL = 2

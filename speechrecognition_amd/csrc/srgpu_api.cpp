@@ -347,7 +347,15 @@ int prof_end(sr_model* m, hipStream_t s, EventPair* ep) {
 
 // kernel-specific model packing (first use) and workspaces for scoring launches of up to n_max frames: growing a
 // workspace frees the old one, which must not happen between launches that are still queued
+// SR_GMM_DEFAULT for a dense table: the fastest kernel that gives the reference's results -- the bit-exact prefilter path for
+// max-approx models; for sum scoring (Mixtures.cpp:719-728) the FP64-MFMA kernel with its fused -log sum exp epilogue: the
+// device exp / log put every sum-mode kernel 1e-12 from the reference anyway, and the dense direct form is 3x slower.
+int resolve_dense_kernel(const sr_model* m, int gmm_kernel) {
+  return gmm_kernel != SR_GMM_DEFAULT ? gmm_kernel : m->max_approx ? SR_GMM_PREFILTER : SR_GMM_MFMA;
+}
+
 int reserve_scoring(sr_model* m, int gmm_kernel, uint64_t n_max) {
+  gmm_kernel = resolve_dense_kernel(m, gmm_kernel);
   if ((gmm_kernel == SR_GMM_MFMA && !m->mfma_packed) || (gmm_kernel == SR_GMM_PREFILTER && !m->pf_packed)) {
     int rc = srhost::ensure_host_tables(m);
     if (rc) return rc;
@@ -379,6 +387,7 @@ int reserve_scoring(sr_model* m, int gmm_kernel, uint64_t n_max) {
 // score frames [f_begin, f_end) of `feats` into `out` (device, row stride m->ld) on stream s_gmm
 int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm_kernel, double* d_out) {
   if (n_frames == 0) return SR_OK;
+  gmm_kernel = resolve_dense_kernel(m, gmm_kernel);
   EventPair ep{};
   {
     int rc = reserve_scoring(m, gmm_kernel, n_frames);
@@ -1296,6 +1305,7 @@ static int align_common(sr_model* m, sr_corpus* c, const uint16_t* automata, con
                         double* out_cost) {
   int rc = check_model(m);
   if (rc) return rc;
+  if (gmm_kernel == SR_GMM_DEFAULT) gmm_kernel = SR_GMM_PREFILTER;  // the aligner scores only its automaton's states: listed, bit-exact
   if (!c || c->model != m) return fail(SR_EINVAL, "corpus does not belong to this model");
   if (!automata || !aut_off || !tdp || !out_states || !out_cost) return fail(SR_EINVAL, "null argument");
   const uint32_t U = c->n_utts;
@@ -1416,6 +1426,7 @@ int sr_path_scores_corpus(sr_model* m, sr_corpus* c, const uint16_t* states, int
   return guarded(__func__, [&]() -> int {
   int rc = check_model(m);
   if (rc) return rc;
+  if (gmm_kernel == SR_GMM_DEFAULT) gmm_kernel = SR_GMM_PREFILTER;  // (frame, state) pairs scored directly, bit-exact
   if (!c || c->model != m) return fail(SR_EINVAL, "corpus does not belong to this model");
   const uint64_t F = c->n_frames;
   if (F == 0) return SR_OK;

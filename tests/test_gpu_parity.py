@@ -43,6 +43,10 @@ def test_golden_scores(name, tmp_path):
         c.check_scores(exact, exact=True)  # bit-identical to MixtureModel::score
     else:
         c.check_scores(exact, exact=False, rtol=1e-12)  # sum mode: device exp/log
+    # SR_GMM_DEFAULT: the prefilter path for max-approx models (those bits), the FP64-MFMA kernel for sum scoring (srgpu.h)
+    with capi.Model.from_mixset(c.mixset_path, c.dim, c.pooling, c.max_approx) as m:
+        dflt = m.score_frames(c.feats, capi.GMM_DEFAULT)
+    assert np.array_equal(dflt.view(np.uint64), (pref if c.max_approx else mfma).view(np.uint64))
     want = c.z["scores"] if "scores" in c.z else None
     if want is not None:
         _assert_scores_close(mfma, want)
@@ -284,6 +288,13 @@ def test_cfg2_single_long_utterance(tmp_path, oracle_lib):
         assert np.array_equal(tbw, ww) and np.array_equal(tbb, wb) and np.array_equal(tbs.view(np.uint64), ws.view(np.uint64))
         words, woff = corpus.recognize(lexh, 200.0, 10.0, capi.GMM_MFMA)
         assert np.array_equal(words, want_words)
+        # the DEFAULT scorer on this geometry: the 8-density-slot refinement variant (gmm_refine_kernel<39, 8, 8, 1>) over one
+        # long utterance, scores against the exact kernel bit for bit, words + traceback against the oracle
+        pref = corpus.score(capi.GMM_PREFILTER)
+        assert np.array_equal(pref.view(np.uint64), corpus.score(capi.GMM_EXACT).view(np.uint64))
+        words, woff, (tbs, tbw, tbb) = corpus.recognize(lexh, 200.0, 10.0, capi.GMM_DEFAULT, traceback=True)
+        assert np.array_equal(words, want_words)
+        assert np.array_equal(tbw, ww) and np.array_equal(tbb, wb) and np.array_equal(tbs.view(np.uint64), ws.view(np.uint64))
         # aligner over the long utterance: 40 words
         rng = np.random.default_rng(25)
         aut = [sil_state]
@@ -465,6 +476,8 @@ def test_em_iteration_matches_reference_model_file(tmp_path, oracle_lib):
     (910, 11, (1, 100), 25, 1.0, 0.5, False),  # ragged up to 100 densities: four chunks, some of them empty
     (911, 6, 130, 12, 1.0, 0.5, False),     # 130 densities: not eligible -> exact kernel, same bits
     (908, 16, 4, 47, 1.0, 0.5, False),      # dim 47: not eligible either
+    (912, 9, 64, 39, 1.0, 0.5, True),       # round 4 (one evaluation per STATE): exact ties ACROSS a state's two chunks
+    (913, 7, (33, 128), 39, 1.0, 0.5, True),  # three / four chunks at dim 39, ties across chunks, non-finite frames below
 ])
 def test_prefilter_scores_are_bit_identical(tmp_path, oracle_lib, seed, S, M, D, scale, var_floor, dup):
     """SR_GMM_PREFILTER must return MixtureModel::score's bits: the bf16 stage may only over-select candidates."""
@@ -476,6 +489,10 @@ def test_prefilter_scores_are_bit_identical(tmp_path, oracle_lib, seed, S, M, D,
             if len(dl) > 1:
                 spec.mean_acc[dl[1]] = spec.mean_acc[dl[0]]; spec.var_acc[dl[1]] = spec.var_acc[dl[0]]
                 spec.mean_w[dl[1]] = spec.mean_w[dl[0]]; spec.var_w[dl[1]] = spec.var_w[dl[0]]
+            for k in range(32, len(dl), 32):  # ... and a copy of the first density in every further 32-slot chunk of the state
+                src, dst = dl[0], dl[min(k + 5, len(dl) - 1)]
+                spec.mean_acc[dst] = spec.mean_acc[src]; spec.var_acc[dst] = spec.var_acc[src]
+                spec.mean_w[dst] = spec.mean_w[src]; spec.var_w[dst] = spec.var_w[src]
     mp = str(tmp_path / "pf.mix")
     synth.write_mixset(mp, spec)
     T = 700  # not a multiple of the 128-frame tile nor of 256
@@ -483,6 +500,10 @@ def test_prefilter_scores_are_bit_identical(tmp_path, oracle_lib, seed, S, M, D,
     feats[5] = 0.0
     feats[6] = 1e-20     # squares underflow in bf16/fp32
     feats[7, 0] = 250.0  # one dominant component
+    if seed >= 912:      # every density of every chunk stays a candidate: all lists, both levels, all chunks
+        feats[9] = np.nan
+        feats[10, 3] = np.inf
+        feats[11, 1] = 1e30
     lex = synth.make_lexicon(max(1, (S - 1) // 3), 3, 1, extra_states_last=(S - 1) % 3)
     o = oracle_lib.Oracle(mp, D, lex)
     want = o.score_matrix(feats)
