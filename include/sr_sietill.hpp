@@ -42,6 +42,11 @@ typedef uint16_t StateIdx;
 inline void check(int rc) {
   if (rc != SR_OK) throw std::runtime_error(sr_last_error());
 }
+// the loaded library must lay its parameter structs out like the header this file was compiled against (srgpu.h)
+inline void check_abi() {
+  static const bool ok = sr_abi_version() == SR_ABI_VERSION;
+  if (!ok) throw std::runtime_error("libsrgpu.so: ABI version differs from the srgpu.h this binding was compiled against");
+}
 
 // ---- FeatureScorer.hpp:12-16 ----------------------------------------------------------------------
 class FeatureScorer {
@@ -123,6 +128,7 @@ class MixtureModel : public FeatureScorer {
                int device = 0, int gmm_kernel = SR_GMM_DEFAULT)
       : dimension(dimension), var_model(var_model), gmm_kernel(gmm_kernel), path_(load_mixtures_from), max_approx_(max_approx),
         device_(device) {
+    check_abi();
     check(sr_model_load_mixset(load_mixtures_from.c_str(), (uint32_t)dimension, (int)var_model, max_approx ? 1 : 0, device, &h_));
     uint32_t d, s;
     uint64_t c;
@@ -245,12 +251,20 @@ class Recognizer {
   }
   Recognizer(Recognizer const&) = delete;
 
+  sr_search_params search_params() const {
+    sr_search_params p = sr_search_params();  // zeroed, then field by field: a field added to the struct cannot shift these
+    p.am_threshold = am_threshold_;
+    p.word_penalty = word_penalty_;
+    p.gmm_kernel = scorer_.gmm_kernel;
+    return p;
+  }
+
   // Recognizer::recognizeSequence_pruned (Recognizer.cpp:103-232)
   void recognizeSequence_pruned(const float* feature_begin, size_t n_frames, std::vector<WordIdx>& output) {
     const uint64_t off[2] = {0, n_frames};
     std::vector<uint32_t> words(std::max<size_t>(n_frames, 1));
     uint64_t woff[2];
-    const sr_search_params p = {am_threshold_, word_penalty_, scorer_.gmm_kernel, 0};
+    const sr_search_params p = search_params();
     check(sr_recognize_batch(scorer_.handle(), net_, &p, feature_begin, off, 1, words.data(), woff));
     output.assign(words.begin(), words.begin() + woff[1]);
   }
@@ -268,7 +282,7 @@ class Recognizer {
     const uint64_t total = corpus.frame_offsets()[n];
     std::vector<uint32_t> words(std::max<uint64_t>(total, 1));
     std::vector<uint64_t> woff(n + 1);
-    const sr_search_params p = {am_threshold_, word_penalty_, scorer_.gmm_kernel, 0};
+    const sr_search_params p = search_params();
     double t0;
     if (devices.size() <= 1 && (devices.empty() || devices[0] == scorer_.device())) {
       t0 = now();
@@ -616,7 +630,10 @@ class LinearSearch {
     std::vector<uint64_t> off(n + 1);
     sr_corpus* c = nullptr;
     check(sr_corpus_upload(scorer_.handle(), corpus.features(), corpus.frame_offsets(), (uint32_t)n, &c));
-    const sr_bigram_params p = {acoustic_pruning_, lm_pruning_, scorer_.gmm_kernel, /*max_word_ends*/ 0, /*flags*/ 0};
+    sr_bigram_params p = sr_bigram_params();  // zeroed, then field by field: a field added to the struct cannot shift these
+    p.acoustic_pruning = acoustic_pruning_;
+    p.lm_pruning = lm_pruning_;
+    p.gmm_kernel = scorer_.gmm_kernel;
     const int rc = sr_recognize_bigram_corpus(scorer_.handle(), c, net_, &p, words.data(), scores.data(), times.data(), off.data());
     sr_corpus_destroy(c);
     check(rc);

@@ -34,6 +34,13 @@ extern "C" {
 #define SR_API
 #endif
 
+/* ABI version of this header.  Bumped whenever a struct below grows or changes layout or an entry point changes its signature
+ * (4: sr_bigram_params gained `flags` in round 3 -- a caller compiled against the 16-byte struct of version 3 would be read 4 bytes
+ * past its end; sr_model_trim, SR_GMM_DEFAULT).  A binding checks `sr_abi_version() == SR_ABI_VERSION` once after loading the
+ * library (capi.py and sr_sietill.hpp do) and zero-initialises the parameter structs field by field. */
+#define SR_ABI_VERSION 4
+SR_API int sr_abi_version(void);
+
 #define SR_OK 0
 #define SR_EINVAL (-1)   /* bad argument (message says which) */
 #define SR_EHIP (-2)     /* HIP runtime error */
@@ -106,7 +113,13 @@ SR_API int sr_corpus_upload(sr_model* m, const float* feats, const uint64_t* fra
  * the corpus has been destroyed); sr_corpus_wait returns the feeder's status.  sr_recognize_batch feeds this way. */
 SR_API int sr_corpus_upload_async(sr_model* m, const float* feats, const uint64_t* frame_off, uint32_t n_utts, sr_corpus** out);
 SR_API int sr_corpus_wait(sr_corpus* c);
+/* A corpus must be destroyed BEFORE the model it was uploaded to.  Its search-path device buffers (features, frame offsets, word and
+ * traceback outputs) are not freed but parked on the model for the next corpus -- sr_recognize_batch creates and destroys one per
+ * call, and nine allocations per batch cost about a millisecond -- if they hold at most SRGPU_SPARE_MB MiB together (default 256;
+ * 0 keeps nothing); one set is kept, until the next upload adopts it, sr_model_trim() or sr_model_destroy(). */
 SR_API int sr_corpus_destroy(sr_corpus* c);
+/* Releases what the model keeps for reuse between calls (the parked buffers above). */
+SR_API int sr_model_trim(sr_model* m);
 
 /* ---- scoring: FeatureScorer::prepare_sequence + score (FeatureScorer.hpp:14-15) -------------------
  * Dense table out[total_frames x n_states] (row-major, host memory): out[t*n_states+s] is what

@@ -114,7 +114,10 @@ inline void gpu_recognize(GpuMixtureScorer const& scorer, Lexicon const& lexicon
   }
   std::vector<uint32_t> words(frame_off[corpus_size] + 1);
   std::vector<uint64_t> out_off(corpus_size + 1);
-  sr_search_params p = {am_threshold, word_penalty, SR_GMM_DEFAULT, 0};
+  sr_search_params p = sr_search_params();  // zeroed, then field by field
+  p.am_threshold = am_threshold;
+  p.word_penalty = word_penalty;
+  p.gmm_kernel = SR_GMM_DEFAULT;
   const int rc = sr_recognize_batch(scorer.handle(), net, &p, *corpus.get_feature_sequence(0).first, frame_off.data(),
                                     corpus_size, words.data(), out_off.data());
   sr_lexicon_destroy(net);
@@ -165,7 +168,10 @@ inline void gpu_recognize(std::vector<GpuMixtureScorer*> const& scorers, Lexicon
   }
   std::vector<uint32_t> words(frame_off[corpus_size] + 1);
   std::vector<uint64_t> out_off(corpus_size + 1);
-  sr_search_params p = {am_threshold, word_penalty, SR_GMM_DEFAULT, 0};
+  sr_search_params p = sr_search_params();  // zeroed, then field by field
+  p.am_threshold = am_threshold;
+  p.word_penalty = word_penalty;
+  p.gmm_kernel = SR_GMM_DEFAULT;
   if (sr_recognize_batch_multi(models.data(), nets.data(), models.size(), &p, *corpus.get_feature_sequence(0).first,
                                frame_off.data(), corpus_size, words.data(), out_off.data(), NULL) != SR_OK) {
     throw std::runtime_error(sr_last_error());

@@ -21,9 +21,11 @@ SEARCH_GENERAL_KERNEL = 1
 SEARCH_SLOT_KERNEL = 2
 BIGRAM_DENSE_STATES = 1
 SR_ECORRUPT = -7
+SR_ABI_VERSION = 4
 
 # every symbol include/srgpu.h declares
 SYMBOLS = [
+    "sr_abi_version", "sr_model_trim",
     "sr_last_error", "sr_device_count", "sr_model_create", "sr_model_load_mixset", "sr_model_destroy", "sr_model_info",
     "sr_corpus_upload", "sr_corpus_upload_async", "sr_corpus_wait", "sr_corpus_destroy", "sr_shard_utterances", "sr_recognize_batch_multi", "sr_score_corpus", "sr_score_frames", "sr_lexicon_create",
     "sr_lexicon_destroy", "sr_lexicon_describe", "sr_recognize_corpus", "sr_traceback_corpus", "sr_traceback_words", "sr_recognize_batch", "sr_align_corpus", "sr_align_corpus_pruned", "sr_path_scores_corpus", "sr_model_create_from_statistics", "sr_model_create_from_accumulated", "sr_mixset_write", "sr_model_set_tying", "sr_model_tying_info", "sr_model_topology", "sr_accumulate_corpus",
@@ -64,12 +66,15 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise FileNotFoundError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
         L = C.CDLL(LIB_PATH)
+        if L.sr_abi_version() != SR_ABI_VERSION:  # the struct layouts below are those of include/srgpu.h version SR_ABI_VERSION
+            raise RuntimeError(f"{LIB_PATH} has ABI version {L.sr_abi_version()}, this binding was written for {SR_ABI_VERSION}")
         L.sr_last_error.restype = C.c_char_p
         vp, u32, u64, i32, dbl = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int, C.c_double
         L.sr_device_count.argtypes = [C.POINTER(i32)]
         L.sr_model_create.argtypes = [i32, u32, u32, vp, vp, vp, vp, vp, i32, C.POINTER(vp)]
         L.sr_model_load_mixset.argtypes = [C.c_char_p, u32, i32, i32, i32, C.POINTER(vp)]
         L.sr_model_destroy.argtypes = [vp]
+        L.sr_model_trim.argtypes = [vp]
         L.sr_model_info.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u64)]
         L.sr_corpus_upload.argtypes = [vp, vp, vp, u32, C.POINTER(vp)]
         L.sr_corpus_destroy.argtypes = [vp]
@@ -172,6 +177,10 @@ class Model:
         if self.h:
             lib().sr_model_destroy(self.h)
             self.h = None
+
+    def trim(self):
+        """sr_model_trim: releases the device buffers the model keeps between calls."""
+        _check(lib().sr_model_trim(self.h))
 
     def __enter__(self):
         return self

@@ -68,7 +68,13 @@ struct CorpusSpare {
   DevBuf<uint32_t> utt_order, out_words, out_count, out_flags;
   DevBuf<double> tb_score;
   DevBuf<uint16_t> tb_word, tb_bkp;
+  size_t bytes() const {
+    return feats.n * 4 + d_frame_off.n * 8 + (utt_order.n + out_words.n + out_count.n + out_flags.n) * 4 + tb_score.n * 8 + (tb_word.n + tb_bkp.n) * 2;
+  }
 };
+// ... kept only up to this size (SRGPU_SPARE_MB, default 256): a one-shot call on a huge corpus must not leave the model holding
+// a corpus-sized allocation; sr_model_trim() releases it at any time
+size_t corpus_spare_cap_bytes();
 
 struct sr_model {
   int device = 0;

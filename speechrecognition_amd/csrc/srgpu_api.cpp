@@ -534,11 +534,20 @@ void corpus_adopt_spare(sr_corpus* c) {
   if (sp) swap_spare(c, *sp);  // (whatever the new corpus held -- nothing -- goes away with sp)
   c->order_chunk_frames = 0;   // the launch order is rebuilt for the new utterances
 }
+size_t corpus_spare_cap_bytes() {
+  static const size_t cap = [] {
+    const char* e = getenv("SRGPU_SPARE_MB");
+    const long mb = e ? atol(e) : 256;
+    return (size_t)(mb < 0 ? 0 : mb) << 20;
+  }();
+  return cap;
+}
 void corpus_donate_spare(sr_corpus* c) {
-  sr_model* m = c->model;
+  sr_model* m = c->model;  // (srgpu.h: a corpus is destroyed BEFORE its model)
   if (!m) return;
   std::unique_ptr<CorpusSpare> sp(new CorpusSpare());
   swap_spare(c, *sp);
+  if (sp->bytes() > corpus_spare_cap_bytes()) return;  // too big to keep: freed on return
   std::lock_guard<std::mutex> lk(m->spare_mu);
   if (!m->spare) m->spare = std::move(sp);  // (else: one spare set is kept, this one is freed on return)
 }
@@ -556,6 +565,8 @@ int check_model(const sr_model* m) {
 extern "C" {
 
 const char* sr_last_error(void) { return g_err; }
+
+int sr_abi_version(void) { return SR_ABI_VERSION; }
 
 int sr_device_count(int* count) {
   return guarded(__func__, [&]() -> int {
@@ -742,6 +753,17 @@ int sr_corpus_upload(sr_model* m, const float* feats, const uint64_t* frame_off,
     return fail(SR_EHIP, "corpus upload: %s", hipGetErrorString(e));
   *out = own.release();
   return SR_OK;
+  });
+}
+
+int sr_model_trim(sr_model* m) {
+  return guarded(__func__, [&]() -> int {
+  int rc = check_model(m);
+  if (rc) return rc;
+  HIP_TRY(hipDeviceSynchronize());
+  std::unique_ptr<CorpusSpare> sp;
+  { std::lock_guard<std::mutex> lk(m->spare_mu); sp = std::move(m->spare); }
+  return SR_OK;  // (sp's buffers are freed here)
   });
 }
 
