@@ -148,7 +148,7 @@ SR_API int sr_lexicon_describe(const sr_lexicon* l, char* out, size_t cap);
 typedef struct {
   double am_threshold; /* "am-threshold", Recognizer.cpp:31 (beam) */
   double word_penalty; /* "word-penalty", Recognizer.cpp:32 */
-  int gmm_kernel;      /* SR_GMM_MFMA, SR_GMM_EXACT or SR_GMM_PREFILTER */
+  int gmm_kernel;      /* SR_GMM_DEFAULT, or SR_GMM_MFMA / SR_GMM_EXACT / SR_GMM_PREFILTER */
   int flags;           /* 0, SR_SEARCH_GENERAL_KERNEL or SR_SEARCH_SLOT_KERNEL (was `reserved`, must be 0 otherwise) */
 } sr_search_params;
 /* Decode every utterance with the general kernel (slots in reference order, sequential boundary replay inline,
@@ -156,7 +156,8 @@ typedef struct {
  * an utterance to it by itself when it meets a negative emission cost; this flag is for cross-checking the two. */
 #define SR_SEARCH_GENERAL_KERNEL 1
 /* Lexica whose words all have at most four positions (and at most 3072 words, score rows that fit the LDS twice) are searched
- * by the word-per-lane kernel (viterbi_words.hip: a word's hypotheses live in registers); this flag keeps them on the
+ * by the word-per-lane kernel (viterbi_words.hip: a word's hypotheses live in registers) -- also where they have more than the
+ * 8192 type-padded positions the slot-per-lane kernel holds (2 731 .. 3 072 three-state words; round 4); this flag keeps them on the
  * slot-per-lane kernel that serves every other lexicon (viterbi_fast.hip).  Same results; for cross-checking the two. */
 #define SR_SEARCH_SLOT_KERNEL 2
 

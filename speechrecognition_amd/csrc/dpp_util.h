@@ -39,6 +39,18 @@ __device__ inline uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t
 __device__ inline void publish_min_f64_lds(double* cell, double v) {
   asm volatile("ds_min_f64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : : "v"(lds_addr(cell)), "v"(v) : "memory");
 }
+// Five LDS ds_min_u32 without return values in one statement, then their wait: cell0 and the four consecutive cells at cells4,
+// a value of 0xFFFFFFFF where a lane has nothing to contribute (the minimum with it is a no-op).  (atomicMin() on an LDS cell goes
+// through the compiler's atomic optimiser: a scalar loop over the active lanes -- s_ff1, v_readlane, s_min per lane -- before ONE
+// atomic; the search kernels call it from the one or two lanes that hold a frame's minimum, five times in a row, on the wave every
+// other wave of the workgroup then waits for at the barrier: 125 of that wave's ~650 instructions per frame, profiles/r4_words_stamps.txt.)
+// The cells are read after a later workgroup barrier, and the compiler's own s_waitcnt before a barrier does not cover an asm: the
+// wait is part of the statement, as above.
+__device__ inline void lds_min5_u32(uint32_t* cell0, uint32_t v0, uint32_t* cells4, uint32_t v1, uint32_t v2, uint32_t v3, uint32_t v4) {
+  asm volatile("ds_min_u32 %0, %1\n\tds_min_u32 %2, %3\n\tds_min_u32 %2, %4 offset:4\n\tds_min_u32 %2, %5 offset:8\n\tds_min_u32 %2, %6 offset:12\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : : "v"(lds_addr(cell0)), "v"(v0), "v"(lds_addr(cells4)), "v"(v1), "v"(v2), "v"(v3), "v"(v4) : "memory");
+}
 // two cells, both atomics in flight together, one wait
 __device__ inline void publish_min2_f64_lds(double* cell0, double v0, double* cell1, double v1) {
   asm volatile("ds_min_f64 %0, %1\n\tds_min_f64 %2, %3\n\ts_waitcnt lgkmcnt(0)"

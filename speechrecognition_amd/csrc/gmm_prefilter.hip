@@ -697,7 +697,11 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
         res[r] = 1e10;  // min_score seed (Mixtures.cpp:699)
         if (nd[r * CH]) {  // wave-uniform (a state without densities keeps the seed; chunk 0 fills first)
           // lanes of one wave instruction now read up to CH panels: slot d of every panel of a state shares a bank pair
+#if defined(SR_R_PROBE) && SR_R_PROBE == 1  // timing probe (wrong results): every lane reads the state's first panel -- no cross-panel bank conflicts
+          const double score = evaluate(panel_raw + (size_t)(r * CH) * state_bytes + (uint32_t)__builtin_ctz(msel | 0x80000000u) * 8u);
+#else
           const double score = evaluate(panel_raw + (size_t)(r * CH) * state_bytes + off + (uint32_t)__builtin_ctz(msel | 0x80000000u) * 8u);
+#endif
           res[r] = msel != 0 ? seeded_min(score) : res[r];
           if (counting) n_eval += (uint32_t)__builtin_popcountll(__ballot(valid));
         }
@@ -707,7 +711,11 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
           // earlier ones are empty).  The batches take the best score so far from the table (shared by the state's chunks).
           const bool is_sel = off == (uint32_t)c * state_bytes;
           const uint32_t rest = is_sel ? msel & (msel - 1) : mk[r * CH + c];
+#if defined(SR_R_PROBE) && SR_R_PROBE == 2  // timing probe (wrong results): nothing goes to the lists
+          (void)rest;
+#else
           if (nd[r * CH + c]) append(r * CH + c, valid && rest != 0, rest, res[r]);
+#endif
         }
       }
       if (valid) {
@@ -727,7 +735,9 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
     // level 1 evaluates each pair's second candidate, level 2 everything after the second.
     const bool last = it + 1 == n_it;
     // table stores issued after the last list store (wave-uniform): SPW/2 row pieces, unless the data-dependent paths ran
-    uint32_t tail_stores = (!chunk_shift && ns == SPW && __any(valid)) ? (uint32_t)(SPW / 2) : 0u;
+    uint32_t tail_stores;
+    if constexpr (CH == 1) tail_stores = (!chunk_shift && ns == SPW && __any(valid)) ? (uint32_t)(SPW / 2) : 0u;
+    else tail_stores = !__any(valid) ? 0u : (ns == SPW && RS >= 2) ? (uint32_t)(RS / 2) : (ns + CH - 1u) / CH;  // pairs, else one store per whole state
     for (;;) {
       uint32_t level, j, n;
       {
@@ -753,10 +763,20 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
       // This wave's earlier list stores must have landed before they are read back.  Stores complete in issue order,
       // and the youngest ones are always table stores nobody reads here (the main pass' row pieces, SPW/2 of them when
       // the workgroup owns SPW whole states; a previous batch's single update): waiting for all but those skips their
-      // HBM round trip.  Mixtures of more than 32 densities read the table below and wait for everything.
-      if (tail_stores == (uint32_t)(SPW / 2)) __builtin_amdgcn_s_waitcnt(0x0F70 | (SPW / 2));  // vmcnt(SPW/2)
-      else if (tail_stores == 1u) __builtin_amdgcn_s_waitcnt(0x0F71);                          // vmcnt(1)
-      else __builtin_amdgcn_s_waitcnt(0x0F70);                                                  // vmcnt(0)
+      // HBM round trip.
+      if constexpr (CH == 1) {
+        if (tail_stores == (uint32_t)(SPW / 2)) __builtin_amdgcn_s_waitcnt(0x0F70 | (SPW / 2));  // vmcnt(SPW/2)
+        else if (tail_stores == 1u) __builtin_amdgcn_s_waitcnt(0x0F71);                          // vmcnt(1)
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                                                  // vmcnt(0)
+      } else {
+        switch (tail_stores) {  // (at most SPW / CH <= 4 stores: one per whole state of a short last workgroup)
+          case 1: __builtin_amdgcn_s_waitcnt(0x0F71); break;
+          case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break;
+          case 3: __builtin_amdgcn_s_waitcnt(0x0F73); break;
+          case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;
+          default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
+        }
+      }
       asm volatile("" ::: "memory");
       const uint32_t at = slot0 + have - n + (live ? (uint32_t)lane : 0u);
       const RingEntry en = ring[at];
@@ -766,9 +786,15 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
       const uint64_t fb = frame_of(lfb);
       load_x_row(fb);
       double* o = a.out + fb * a.ld + ((s0 + j) >> chunk_shift);
-      // a mixture of more than 32 densities: the table entry is shared by the state's pseudo-states and may have been
-      // lowered through another one since -- take it from the table (this wave's own stores have landed, see above)
-      if (chunk_shift) cur = *o;
+      // A mixture of more than 32 densities: the table entry is shared by the state's pseudo-states and may have been lowered
+      // through another one since the pair was listed.  Round 4: the batch does not read it back (round 3 did: a dependent
+      // global round trip behind a full vmcnt(0) drain per batch -- 12.7 us per batch against 5 us for 32-density states, 17 of
+      // configs[4]'s 49 ms, gpurun_out/r4_ab_refine_probe_cfg5.txt) -- it lowers the entry with a floating-point atomic minimum
+      // where its candidate beats the score the pair was listed with: the entry ends as the minimum over all candidates whatever
+      // the order (a NaN score fails `score < cur` and is never sent; scores are never -0).
+      if constexpr (CH == 1) {
+        if (chunk_shift) cur = *o;  // (never taken in this instantiation; part of the round-3 schedule, see chunk_shift)
+      }
       const double before = cur;
       const unsigned char* panel = panel_raw + (size_t)j * state_bytes;
       do {  // level 1: exactly one round (every live lane has a second candidate); level 2: until every lane is done
@@ -791,8 +817,15 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
       // the table update comes last: it is the one store the next batch need not wait for
       asm volatile("" ::: "memory");
       const bool lower = live && cur < before;
-      tail_stores = (!chunk_shift && __any(lower)) ? 1u : 0u;
-      if (lower) *o = cur;
+      if constexpr (CH == 1) {
+        tail_stores = (!chunk_shift && __any(lower)) ? 1u : 0u;
+        if (lower) *o = cur;
+      } else {
+        tail_stores = __any(lower) ? 1u : 0u;
+        // global_atomic_min_f64 without a return value: issued behind this wave's earlier stores to the same entry (one wave owns a
+        // frame's row pieces and lists; vector memory operations of a wave reach an address in issue order)
+        if (lower) (void)__builtin_amdgcn_global_atomic_fmin_f64((__attribute__((address_space(1))) double*)o, cur);
+      }
     }
   }
   if (a.n_refined) {

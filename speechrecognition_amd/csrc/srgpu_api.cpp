@@ -985,7 +985,8 @@ int sr_lexicon_describe(const sr_lexicon* l, char* out, size_t cap) {
   DecodeArgs da{};
   da.words.info = l->w_plain_len ? l->w_info.p : nullptr;
   da.ld = l->model ? l->model->ld : 0;
-  if (l->big) snprintf(out, cap, "big (%u positions: hypotheses in device memory)", l->n_slots);
+  if (l->big && decode_words_applies(da)) snprintf(out, cap, "words %u x %u plain %u%s (replay: big, %u positions)", l->w_nw, l->w_nt, l->w_plain_len, l->w_general ? " general" : "", l->n_slots);
+  else if (l->big) snprintf(out, cap, "big (%u positions: hypotheses in device memory)", l->n_slots);
   else if (decode_words_applies(da)) snprintf(out, cap, "words %u x %u plain %u%s", l->w_nw, l->w_nt, l->w_plain_len, l->w_general ? " general" : "");
   else snprintf(out, cap, "slots (%u type-padded positions)", l->f_n);
   return SR_OK;
@@ -1080,7 +1081,16 @@ int sr_recognize_corpus(sr_model* m, sr_corpus* c, sr_lexicon* l, const sr_searc
     da.scores = m->scores[buf].p; da.frame_base = ch.f0; da.utt_first = ch.u0; da.n_utts = ch.u1 - ch.u0;
     EventPair ep{};
     if ((rc = prof_begin(m, s_search, 1, &ep))) return rc;
-    HIP_TRY(l->big ? launch_decode_big(da, c->big_ws.p, s_search) : launch_decode(da, s_search));
+    if (l->big && !da.force_general && !da.force_slots && decode_words_applies(da)) {
+      // more than 8192 type-padded positions, but words of at most four: the word-per-lane kernel does not depend on the slot count
+      // (ADVICE r3); what it flags (a negative emission cost) is redone by the device-memory kernel, which exits at once elsewhere
+      HIP_TRY(launch_decode_words(da, s_search));
+      da.only_flagged = 1;
+      HIP_TRY(launch_decode_big(da, c->big_ws.p, s_search));
+      da.only_flagged = 0;
+    } else {
+      HIP_TRY(l->big ? launch_decode_big(da, c->big_ws.p, s_search) : launch_decode(da, s_search));
+    }
     if ((rc = prof_end(m, s_search, &ep))) return rc;
     HIP_TRY(hipEventRecord(m->ev_consumed[buf], s_search));
     if (m->profiling) m->prof.search_bytes += (8.0 * m->n_states + 4.0 * l->n_slots) * (double)(ch.f1 - ch.f0);

@@ -372,6 +372,7 @@ __global__ __launch_bounds__(NT) void decode_big_kernel(DecodeArgs a, unsigned c
   const uint32_t P = a.net.n_slots;
   const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const uint32_t u = a.utt_order ? a.utt_order[a.utt_first + blockIdx.x] : a.utt_first + blockIdx.x;
+  if (a.only_flagged && !(a.out_flags[u] & kFlagReplay)) return;  // workgroup-uniform: replay of the word-per-lane kernel, nothing to redo
   const uint64_t f0 = a.frame_off[u];
   const uint32_t T = (uint32_t)(a.frame_off[u + 1] - f0);
   const double* row0 = a.scores + (f0 - a.frame_base) * a.ld;

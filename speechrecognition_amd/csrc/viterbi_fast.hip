@@ -374,16 +374,17 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
           if (nr[i]) {
             const double v = nv[i];
             const uint32_t o = og[i] & 0xFFFFu;
-            if (v == m_we) {  // traceback[t] = the FIRST minimal surviving word end (:199-205): settled by the atomic, written next frame
-              atomicMin(&c_widx[par], o);
+            const bool is_min = v == m_we;
+            if (is_min) {  // traceback[t] = the FIRST minimal surviving word end (:199-205): settled by the atomic, written next frame
               // (a lane may hold several of them: it keeps the one with the smallest original index, the only one that can win)
               if (!pend || o < pend_o) { pend_o = o; pend_p = slot_of(i); pend_b = nb[i]; pend_v = v; }
               pend = true;
             }
-            if (v + 0.0 + tf == m_we + 0.0 + tf) atomicMin(&ef_nxt[0], o);
-            if (v + 0.0 + ts == m_we + 0.0 + ts) atomicMin(&ef_nxt[1], o);
-            if (v + wp_word + tf == m_we + wp_word + tf) atomicMin(&ef_nxt[2], o);
-            if (v + wp_word + ts == m_we + wp_word + ts) atomicMin(&ef_nxt[3], o);
+            // all five atomic minima in one statement (dpp_util.h: no wave-reduction loops, the wait included); 0xFFFFFFFF = nothing
+            const uint32_t none = 0xFFFFFFFFu;
+            lds_min5_u32(&c_widx[par], is_min ? o : none, ef_nxt,
+                         v + 0.0 + tf == m_we + 0.0 + tf ? o : none, v + 0.0 + ts == m_we + 0.0 + ts ? o : none,
+                         v + wp_word + tf == m_we + wp_word + tf ? o : none, v + wp_word + ts == m_we + wp_word + ts ? o : none);
           }
         }
       }

@@ -65,7 +65,11 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
   uint32_t* e_first = c_widx + 3;                                   // [3][4] first word-end original index per boundary class
   uint32_t* s_bad = e_first + 12;                                   // [1]
   unsigned char* rows_lds = smem + kWordsCellBytes;
-  const uint32_t tid = threadIdx.x, nt = blockDim.x, wave = tid >> 6, lane = tid & 63, n_waves = nt >> 6;
+  const uint32_t tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, n_waves = nt >> 6;
+  // the wave's index as a SCALAR: the compiler cannot know that threadIdx.x >> 6 is wave-uniform, and with it in a vector register
+  // the piece loop of issue_row below became an exec-masked vector loop with a v_readfirstlane per piece -- 18 instructions per
+  // 1 KB piece, 15 % of a frame at configs[2] (tools/words_stamps_r4.py, profiles/r4_words_stamps.txt)
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
   const uint32_t row_bytes = a.ld * 8u, row_pad = (row_bytes + 16u + 1023u) & ~1023u;  // row, then the +inf cell
 
   const uint32_t u = a.utt_order ? a.utt_order[a.utt_first + blockIdx.x] : a.utt_first + blockIdx.x;
@@ -123,15 +127,17 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
   __syncthreads();
   if (tid < 4 && init_is_end) e_first[tid] = 0;  // "frame 0": the initial hypothesis is a word end of index 0 in every class
 
+  const uint32_t n_full = row_bytes >> 10, tail_bytes = row_bytes & 1023u;  // whole 1 KB pieces of a row; what the last, short piece holds
   auto issue_row = [&](uint32_t frame /* 1-based */) {  // row of `frame` -> buffer frame & 1; every wave copies its share of the pieces
-    const unsigned char* src = reinterpret_cast<const unsigned char*>(row0 + (uint64_t)(frame - 1) * a.ld);
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(row0 + (uint64_t)(frame - 1) * a.ld) + lane * 16u;
     unsigned char* dst = rows_lds + (frame & 1u) * row_pad;
-    for (uint32_t piece = wave; piece * 1024u < row_bytes; piece += n_waves) {
-      const uint32_t off = piece * 1024u + lane * 16u;
-      if (off < row_bytes)  // (a row is a multiple of 64 bytes; the last piece may be short)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
-                                         (__attribute__((address_space(3))) void*)(dst + piece * 1024u), 16, 0, 0);
-    }
+    uint32_t piece = wave;  // (scalar loop: one s_add per piece for the source, one for M0)
+    for (; piece < n_full; piece += n_waves)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024u),
+                                       (__attribute__((address_space(3))) void*)(dst + piece * 1024u), 16, 0, 0);
+    if (piece == n_full && lane * 16u < tail_bytes)  // (a row is a multiple of 64 bytes: the last piece may be short)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024u),
+                                       (__attribute__((address_space(3))) void*)(dst + piece * 1024u), 16, 0, 0);
   };
   if (T > 0) { issue_row(1); __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0)
   __syncthreads();
@@ -337,17 +343,18 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
         const double v = v_end[k];
         if (v <= near) {
           const uint32_t o = o_end[k];
-          if (v == m_we) {  // traceback[t] = the FIRST minimal surviving word end (:199-205): settled by the atomic, written after the next barrier
-            atomicMin(&c_widx[r], o);
+          const bool is_min = v == m_we;
+          if (is_min) {  // traceback[t] = the FIRST minimal surviving word end (:199-205): settled by the atomic, written after the next barrier
             // (a lane may hold several of them: it keeps the one with the smallest original index, the only one that can win)
             if (!pend || o < pend_o) { pend_o = o; pend_w = word[k]; pend_b = b_end[k]; pend_v = v; }
             pend = true;
           }
-          // first word end per boundary class whose candidate (score + word penalty + tdp) equals the minimum's after rounding
-          if (v + 0.0 + tf == m_we + 0.0 + tf) atomicMin(&ef_nxt[0], o);
-          if (v + 0.0 + ts == m_we + 0.0 + ts) atomicMin(&ef_nxt[1], o);
-          if (v + wp_word + tf == m_we + wp_word + tf) atomicMin(&ef_nxt[2], o);
-          if (v + wp_word + ts == m_we + wp_word + ts) atomicMin(&ef_nxt[3], o);
+          // ... and the first word end per boundary class whose candidate (score + word penalty + tdp) equals the minimum's after
+          // rounding; all five atomic minima in one statement (dpp_util.h), 0xFFFFFFFF = nothing to contribute
+          const uint32_t none = 0xFFFFFFFFu;
+          lds_min5_u32(&c_widx[r], is_min ? o : none, ef_nxt,
+                       v + 0.0 + tf == m_we + 0.0 + tf ? o : none, v + 0.0 + ts == m_we + 0.0 + ts ? o : none,
+                       v + wp_word + tf == m_we + wp_word + tf ? o : none, v + wp_word + ts == m_we + wp_word + ts ? o : none);
         }
       }
     }

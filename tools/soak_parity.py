@@ -1,8 +1,11 @@
 """Randomised soak of the GPU path against the CPU oracle: random lexica / mixtures / dims / beams / utterance sets,
 scores (prefilter, exact) bit-identical, words + tracebacks + alignments identical, bigram search identical.
-usage: python tools/soak_parity.py [n_cases] [seed] [ragged|short]   (synth.make_ragged_lexicon instead of the uniform lexicon;
-short: words of one to four positions -- the word-per-lane search kernel, cross-checked against the slot-per-lane kernel)"""
-import os, sys, tempfile, time
+usage: python tools/soak_parity.py [n_cases] [seed] [ragged|short] [--ledger FILE]
+(ragged: synth.make_ragged_lexicon instead of the uniform lexicon; short: words of one to four positions -- the word-per-lane search
+kernel, cross-checked against the slot-per-lane kernel.)  --ledger appends ONE JSON line per run -- seed, generator, cases run, the
+first failing case if any, wall time, the commit and kernel-source hash of the library under test -- to FILE; the lines judged are
+kept under profiles/r4_soak.jsonl."""
+import json, os, sys, tempfile, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from speechrecognition_amd import capi, synth
@@ -24,7 +27,7 @@ def run_case(case, seed0=0, ragged=False, tmp=None):
     if spw * reps < 2:
         reps = 2  # (the decoder wants a word with two or more positions: sr_lexicon_create's documented limit)
     D = int(rng.choice([4, 12, 25, 39, 46, 50]))
-    Mhi = int(rng.choice([1, 3, 8, 33, 70]))
+    Mhi = int(rng.choice([1, 3, 8, 33, 70, 100]))  # (33 / 70 / 100: two, three and four 32-slot chunks per state in the refinement)
     if W >= 1000:
         Mhi = min(Mhi, 3)
     lex = synth.make_ragged_lexicon(W, rng, short=ragged == "short") if ragged else synth.make_lexicon(W, spw, reps)
@@ -105,13 +108,43 @@ def run_case(case, seed0=0, ragged=False, tmp=None):
     return tag
 
 
+def ledger_line(seed0, generator, n_cases, done, failure, secs):
+    import hashlib
+    from speechrecognition_amd import build as B
+    csrc = os.path.join(os.path.dirname(os.path.abspath(B.__file__)), "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode()); h.update(open(os.path.join(csrc, name), "rb").read())
+    info = B.build_info()
+    return {"tool": "tools/soak_parity.py", "seed": seed0, "generator": generator or "uniform", "cases_asked": n_cases, "cases_passed": done,
+            "first_failure": failure, "wall_s": round(secs, 1), "git_head": info.get("git_head", "unknown") + ("+dirty" if info.get("dirty") else ""),
+            "kernel_sources_sha16": h.hexdigest()[:16], "library": os.environ.get("SRGPU_LIB", "in-tree libsrgpu.so"),
+            "checks": "scores prefilter+exact == oracle (uint64); words, traceback, full+pruned alignments == oracle; word-per-lane == slot kernel; "
+                      "bigram register layout == dense layout == oracle restatement"}
+
+
 if __name__ == "__main__":
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    ragged = sys.argv[3] if len(sys.argv) > 3 and sys.argv[3] in ("ragged", "short") else False
+    argv = list(sys.argv[1:])
+    ledger = None
+    if "--ledger" in argv:
+        i = argv.index("--ledger"); ledger = argv[i + 1]; del argv[i:i + 2]
+    n_cases = int(argv[0]) if len(argv) > 0 else 50
+    seed0 = int(argv[1]) if len(argv) > 1 else 0
+    ragged = argv[2] if len(argv) > 2 and argv[2] in ("ragged", "short") else False
     tmp = tempfile.mkdtemp()
     t_start = time.time()
-    for case in range(n_cases):
-        tag = run_case(case, seed0, ragged, tmp)
-        print(f"ok {tag}  [{time.time() - t_start:.0f} s]", flush=True)
+    done, failure = 0, None
+    try:
+        for case in range(n_cases):
+            tag = run_case(case, seed0, ragged, tmp)
+            done += 1
+            print(f"ok {tag}  [{time.time() - t_start:.0f} s]", flush=True)
+    except AssertionError as e:
+        failure = {"case": done, "what": str(e)[:400]}
+        raise
+    finally:
+        if ledger:
+            with open(ledger, "a") as f:
+                f.write(json.dumps(ledger_line(seed0, ragged, n_cases, done, failure, time.time() - t_start)) + "\n")
     print("soak passed:", n_cases, "cases")
