@@ -135,6 +135,7 @@ int corpus_from_segments(sr_model* m, std::vector<Segment> segments, const uint6
   sr_corpus* c = new sr_corpus();
   std::unique_ptr<sr_corpus, int (*)(sr_corpus*)> own(c, sr_corpus_destroy);
   c->model = m; c->n_utts = n_utts; c->n_frames = F;
+  srhost::corpus_register(c);
   c->frame_off.assign(frame_off, frame_off + n_utts + 1);
   srhost::corpus_adopt_spare(c);
   if ((e = c->feats.ensure((size_t)total + 64)) != hipSuccess || (e = c->d_frame_off.upload(frame_off, n_utts + 1)) != hipSuccess)

@@ -115,6 +115,8 @@ struct sr_model {
   std::atomic<bool> staging_busy{false};
   std::mutex spare_mu;
   std::unique_ptr<CorpusSpare> spare;  // of the last corpus destroyed while none was kept
+  std::vector<sr_corpus*> corpora;     // live corpora of this model (under spare_mu): sr_model_destroy clears their `model` links, so that a
+                                       // corpus destroyed AFTER its model -- against srgpu.h -- frees its buffers without touching the freed model
   // streams / workspace
   hipStream_t s_gmm = nullptr, s_search = nullptr;
   DevBuf<double> scores[2];
@@ -204,6 +206,7 @@ int corpus_ready(sr_corpus* c, uint64_t f0, uint64_t f1, hipStream_t stream);
 bool corpus_upload_in_flight(const sr_corpus* c);
 void feeder_join(sr_corpus* c);  // blocks until the feeder thread (if any) has finished, frees its staging buffers
 // (srgpu_api.cpp) a new corpus takes over the buffers its model kept from the last destroyed one / a dying corpus leaves them
+void corpus_register(sr_corpus* c);     // after c->model is set
 void corpus_adopt_spare(sr_corpus* c);
 void corpus_donate_spare(sr_corpus* c);
 }  // namespace srhost

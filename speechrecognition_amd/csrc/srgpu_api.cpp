@@ -527,6 +527,11 @@ static void swap_spare(sr_corpus* c, CorpusSpare& sp) {
   c->out_count.swap(sp.out_count); c->out_flags.swap(sp.out_flags); c->tb_score.swap(sp.tb_score); c->tb_word.swap(sp.tb_word);
   c->tb_bkp.swap(sp.tb_bkp);
 }
+void corpus_register(sr_corpus* c) {
+  sr_model* m = c->model;
+  std::lock_guard<std::mutex> lk(m->spare_mu);
+  m->corpora.push_back(c);
+}
 void corpus_adopt_spare(sr_corpus* c) {
   sr_model* m = c->model;
   std::unique_ptr<CorpusSpare> sp;
@@ -547,8 +552,9 @@ void corpus_donate_spare(sr_corpus* c) {
   if (!m) return;
   std::unique_ptr<CorpusSpare> sp(new CorpusSpare());
   swap_spare(c, *sp);
-  if (sp->bytes() > corpus_spare_cap_bytes()) return;  // too big to keep: freed on return
   std::lock_guard<std::mutex> lk(m->spare_mu);
+  m->corpora.erase(std::remove(m->corpora.begin(), m->corpora.end(), c), m->corpora.end());
+  if (sp->bytes() > corpus_spare_cap_bytes()) return;  // too big to keep: freed on return
   if (!m->spare) m->spare = std::move(sp);  // (else: one spare set is kept, this one is freed on return)
 }
 }  // namespace srhost
@@ -695,6 +701,11 @@ int sr_model_destroy(sr_model* m) {
   (void)hipSetDevice(m->device);
   (void)hipDeviceSynchronize();
   for (auto& ep : m->events) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+  {  // corpora that outlive the model (srgpu.h asks for the other order) must not reach into it when they are destroyed
+    std::lock_guard<std::mutex> lk(m->spare_mu);
+    for (sr_corpus* c : m->corpora) c->model = nullptr;
+    m->corpora.clear();
+  }
   m->dens_mean.release(); m->dens_var.release();
   m->dens_off.release(); m->means.release(); m->inv_vars.release(); m->norm.release(); m->logw.release();
   m->apack.release(); m->blk_meta.release(); m->grp_state.release();
@@ -744,6 +755,7 @@ int sr_corpus_upload(sr_model* m, const float* feats, const uint64_t* frame_off,
   sr_corpus* c = new sr_corpus();
   std::unique_ptr<sr_corpus, int (*)(sr_corpus*)> own(c, sr_corpus_destroy);
   c->model = m; c->n_utts = n_utts; c->n_frames = F;
+  srhost::corpus_register(c);
   c->frame_off.assign(frame_off, frame_off + n_utts + 1);
   srhost::corpus_adopt_spare(c);
   hipError_t e;
@@ -821,6 +833,7 @@ int sr_score_frames(sr_model* m, const float* feats, uint64_t n_frames, int gmm_
   sr_corpus* c = new sr_corpus();
   std::unique_ptr<sr_corpus, int (*)(sr_corpus*)> own(c, sr_corpus_destroy);
   c->model = m; c->n_utts = 1; c->n_frames = n_frames; c->frame_off.assign(off, off + 2);
+  srhost::corpus_register(c);
   hipError_t e;
   if ((e = c->feats.ensure((size_t)n_frames * m->dim + 64)) != hipSuccess ||
       (n_frames > 0 && (e = hipMemcpy(c->feats.p, feats, (size_t)n_frames * m->dim * sizeof(float), hipMemcpyHostToDevice)) != hipSuccess))

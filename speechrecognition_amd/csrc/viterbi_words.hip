@@ -118,8 +118,9 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
   if (tid == 12) *s_bad = 0;
   // (Compiling the frame loop a second time for waves whose groups are all plain -- straight-line code, no dispatch on the group
   // kind -- was measured too: 2.30 ms against 2.22, 126 registers and scratch against 119.)
-  // (Fetching rows two frames ahead into three buffers was measured: 3.31 ms per step against 2.99 with the same geometry -- the
-  // frame does not wait for its row; and the third buffer costs the second workgroup per CU, which is worth 2.99 -> 2.24 ms.)
+  // (Round 3: fetching rows two frames ahead into THREE buffers was measured, 3.31 ms per step against 2.99 with the same geometry,
+  // and the third buffer costs the second workgroup per CU, which is worth 2.99 -> 2.24 ms.  Round 4 gets the longer flight time
+  // from two buffers by issuing the copy right behind the barrier, see the frame loop.)
   if (tid < 2) *reinterpret_cast<double*>(rows_lds + tid * row_pad + row_bytes) = kInfF;
   const bool init_is_end = a.words.init_is_end;
   double m_we = init_is_end ? 0.0 : kInfF;  // minimum over the word ends that survived the previous frame (uniform)
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
   };
   if (T > 0) { issue_row(1); __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0)
   __syncthreads();
+  if (T > 1) issue_row(2);  // (waited for before the barrier of frame 1)
 
   uint64_t bad = misplaced ? ~0ull : 0ull;  // lanes that met an emission cost that is not >= 0 (scalar mask, looked at after the last frame)
   // the lane that may own traceback[t]: it held the word-end minimum of frame t; settled by the atomic, written one barrier later
@@ -160,9 +162,19 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
   };
 
   uint32_t r = 1, r_prev = 0;  // t % 3, (t - 1) % 3
+#if defined(SR_WORDS_PROBE) && SR_WORDS_PROBE == 1
+  // timing probe (wrong results): the row copies, their wait and the barrier alone -- how fast can this launch geometry stream the table?
+  for (uint32_t t = 1; t <= T; t++) {
+    const double e0 = *reinterpret_cast<const double*>(rows_lds + (t & 1u) * row_pad + st[0][0]);
+    sc[0][0] = dmin(sc[0][0], e0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    if (t + 2 <= T) issue_row(t + 2);
+  }
+  if (sc[0][0] == 12345.0) a.tb_score[tb0] = 1.0;
+#else
   for (uint32_t t = 1; t <= T; t++) {
     const uint32_t bkp_new = (t - 1) & 0xFFFFu;
-    if (t + 1 <= T) issue_row(t + 1);
     const unsigned char* row_l = rows_lds + (t & 1u) * row_pad;
     const uint64_t we_in = m_we != kInfF ? ~0ull : 0ull;  // uniform: a word end survived the previous frame -- else every boundary candidate is +inf
     // the collapsed word-boundary candidate of a plain word before its emission cost: cur_hyp->score + word_penalty + tdp
@@ -282,6 +294,11 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
     if ((lane & 15u) == 0) publish_min2_f64_lds(&c_best[r], my_best, &c_we[r], my_we);  // (atomics + their wait: dpp_util.h)
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of the next row have landed; the barrier publishes them
     __syncthreads();
+    // Row t + 2 goes into the buffer frame t has just finished with: every wave read its emission costs (phase A) before this
+    // barrier and phase C reads none, so the copy has phase C and phases A and B of frame t + 1 to land in -- a whole frame, where
+    // round 3 issued row t + 1 at the top of frame t and gave it phases A and B only (stamps: 620 cycles of a 7 650-cycle frame
+    // in the vmcnt wait and most of the 1 700 at the barrier at configs[2], profiles/r4_words_stamps.txt).  Still two row buffers.
+    if (t + 2 <= T) issue_row(t + 2);
 
     // ---- C: prune, word-end bookkeeping ------------------------------------------------------------------------------------
     const double best = c_best[r], we = c_we[r];
@@ -367,6 +384,7 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
       r_prev = r; r = r_next;
     }
   }
+#endif
   __syncthreads();
   if (T > 0) flush_pending(T);
 

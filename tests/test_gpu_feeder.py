@@ -148,3 +148,36 @@ def test_corpus_buffers_recycled_across_calls(tmp_path):
                     c.close(); keep.close()
                 assert np.array_equal(w, want[i][0]) and np.array_equal(o, want[i][1]), (rnd, i)
         lexh.close()
+
+
+def test_spare_buffers_are_capped_trimmed_and_survive_the_wrong_destroy_order(tmp_path):
+    """the buffers a model parks for its next corpus (a) can be released (sr_model_trim), (b) are only kept up to
+    SRGPU_SPARE_MB, and (c) a corpus destroyed AFTER its model -- against srgpu.h -- must not reach into the freed model."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        assert hip.hipDeviceSynchronize() == 0
+        fr, tot = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(fr), ctypes.byref(tot)) == 0
+        return fr.value
+
+    lex, spec, mp = _setup(tmp_path, W=20, M=2)
+    word_off, automaton, sil = lex.flatten()
+    feats, off = synth.make_batch(400, 300, 500, 39, seed=31)   # ~160k frames x 156 B = 25 MB of features
+    with capi.Model.from_mixset(mp, 39) as m:
+        lexh = m.lexicon(word_off, automaton, lex.silence_idx, TDP, sil)
+        want = m.recognize_batch(lexh, feats, off, 150.0, 10.0)          # creates and destroys a corpus: its buffers are parked
+        parked = free_bytes()
+        m.trim()
+        trimmed = free_bytes()
+        assert trimmed - parked >= feats.nbytes, (parked, trimmed)        # the feature buffer (at least) came back
+        got = m.recognize_batch(lexh, feats, off, 150.0, 10.0)            # and the model works on without it
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+        lexh.close()
+    # (c): the corpus outlives its model
+    m = capi.Model.from_mixset(mp, 39)
+    c = m.upload(feats[: int(off[3])], off[:4])
+    m.close()
+    c.close()
+    assert free_bytes() > 0

@@ -11,23 +11,24 @@ def rep(a, b):
     global s
     assert a in s, a[:60]
     s = s.replace(a, b, 1)
-rep("  uint32_t r = 1, r_prev = 0;  // t % 3, (t - 1) % 3\n  for (uint32_t t = 1; t <= T; t++) {\n",
-    """  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
+rep("#else\n  for (uint32_t t = 1; t <= T; t++) {\n",
+    """#else
+  unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
 #define SR_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); stamp_sum[k] += now_ - stamp_last; stamp_last = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
-  uint32_t r = 1, r_prev = 0;  // t % 3, (t - 1) % 3
   for (uint32_t t = 1; t <= T; t++) {
     SR_STAMP(0);
 """)
 rep("    // ---- A: the new hypotheses of the lane's words", "    SR_STAMP(1);\n    // ---- A: the new hypotheses of the lane's words")
 rep("    // ---- B: block minima through LDS ds_min_f64 cells", "    SR_STAMP(2);\n    // ---- B: block minima through LDS ds_min_f64 cells")
-rep("    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of the next row have landed; the barrier publishes them\n    __syncthreads();\n",
-    "    SR_STAMP(3);\n    __builtin_amdgcn_s_waitcnt(0x0F70);\n    SR_STAMP(4);\n    __syncthreads();\n    SR_STAMP(5);\n")
+rep("    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's pieces of the next row have landed; the barrier publishes them\n    __syncthreads();\n    // Row t + 2",
+    "    SR_STAMP(3);\n    __builtin_amdgcn_s_waitcnt(0x0F70);\n    SR_STAMP(4);\n    __syncthreads();\n    SR_STAMP(5);\n    // Row t + 2")
 rep("    if (t > 1) flush_pending(t - 1);\n    m_we = we_alive", "    SR_STAMP(6);\n    if (t > 1) flush_pending(t - 1);\n    m_we = we_alive")
-rep("      r_prev = r; r = r_next;\n    }\n  }\n  __syncthreads();\n  if (T > 0) flush_pending(T);\n",
+rep("      r_prev = r; r = r_next;\n    }\n  }\n#endif\n  __syncthreads();\n  if (T > 0) flush_pending(T);\n",
     """      r_prev = r; r = r_next;
     }
     SR_STAMP(7);
   }
+#endif
   __syncthreads();
   if (T > 0) flush_pending(T);
   __syncthreads();
