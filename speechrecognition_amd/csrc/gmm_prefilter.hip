@@ -697,11 +697,7 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
         res[r] = 1e10;  // min_score seed (Mixtures.cpp:699)
         if (nd[r * CH]) {  // wave-uniform (a state without densities keeps the seed; chunk 0 fills first)
           // lanes of one wave instruction now read up to CH panels: slot d of every panel of a state shares a bank pair
-#if defined(SR_R_PROBE) && SR_R_PROBE == 1  // timing probe (wrong results): every lane reads the state's first panel -- no cross-panel bank conflicts
-          const double score = evaluate(panel_raw + (size_t)(r * CH) * state_bytes + (uint32_t)__builtin_ctz(msel | 0x80000000u) * 8u);
-#else
           const double score = evaluate(panel_raw + (size_t)(r * CH) * state_bytes + off + (uint32_t)__builtin_ctz(msel | 0x80000000u) * 8u);
-#endif
           res[r] = msel != 0 ? seeded_min(score) : res[r];
           if (counting) n_eval += (uint32_t)__builtin_popcountll(__ballot(valid));
         }
@@ -711,11 +707,7 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
           // earlier ones are empty).  The batches take the best score so far from the table (shared by the state's chunks).
           const bool is_sel = off == (uint32_t)c * state_bytes;
           const uint32_t rest = is_sel ? msel & (msel - 1) : mk[r * CH + c];
-#if defined(SR_R_PROBE) && SR_R_PROBE == 2  // timing probe (wrong results): nothing goes to the lists
-          (void)rest;
-#else
           if (nd[r * CH + c]) append(r * CH + c, valid && rest != 0, rest, res[r]);
-#endif
         }
       }
       if (valid) {

@@ -162,17 +162,6 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
   };
 
   uint32_t r = 1, r_prev = 0;  // t % 3, (t - 1) % 3
-#if defined(SR_WORDS_PROBE) && SR_WORDS_PROBE == 1
-  // timing probe (wrong results): the row copies, their wait and the barrier alone -- how fast can this launch geometry stream the table?
-  for (uint32_t t = 1; t <= T; t++) {
-    const double e0 = *reinterpret_cast<const double*>(rows_lds + (t & 1u) * row_pad + st[0][0]);
-    sc[0][0] = dmin(sc[0][0], e0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-    if (t + 2 <= T) issue_row(t + 2);
-  }
-  if (sc[0][0] == 12345.0) a.tb_score[tb0] = 1.0;
-#else
   for (uint32_t t = 1; t <= T; t++) {
     const uint32_t bkp_new = (t - 1) & 0xFFFFu;
     const unsigned char* row_l = rows_lds + (t & 1u) * row_pad;
@@ -384,7 +373,6 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
       r_prev = r; r = r_next;
     }
   }
-#endif
   __syncthreads();
   if (T > 0) flush_pending(T);
 
