@@ -1,6 +1,6 @@
 """GPU tests of the guarded traceback walk (csrc/traceback.h): the device walker that ends every search kernel, run alone
 through sr_traceback_corpus on dumps the search itself produced -- and on corrupted ones, which must come back as
-SR_ECORRUPT instead of being followed (round 2's unexplained GPU memory fault)."""
+SR_ECORRUPT instead of being followed (round 2's unexplained GPU memory fault, DESIGN.md section 8 and DESIGN_HISTORY.md section 8.1)."""
 import numpy as np
 import pytest
 
@@ -149,7 +149,7 @@ def test_ragged_lexica_sample_of_the_soak(tmp_path, oracle_lib):
     """A fixed sample of tools/soak_parity.py's ragged cases (synth.make_ragged_lexicon: silence anywhere in the word list,
     one-position words beside 40-state ones, cloned words, words that begin in silence) through scoring, search with
     traceback, both aligners and the bigram search, everything against the oracle.  The full soak (hundreds of cases) is a
-    tool, not a test: DESIGN.md section 8 records its counts."""
+    tool, not a test: DESIGN_HISTORY.md section 8 records its counts."""
     import importlib.util, os
     spec = importlib.util.spec_from_file_location("soak_parity", os.path.join(os.path.dirname(__file__), "..", "tools", "soak_parity.py"))
     soak = importlib.util.module_from_spec(spec)

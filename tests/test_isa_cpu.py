@@ -3,7 +3,7 @@
 
   (i)   every LDS `ds_min_f64` of the search kernels is followed by `s_waitcnt lgkmcnt(0)` before the next `s_barrier`.  The
         atomics are inline asm, so the compiler's own wait before a barrier does not cover them: round 3 shipped a frame loop
-        without the wait for a while and one traceback entry in ~1e5 came out wrong, run to run (DESIGN 4.4a);
+        without the wait for a while and one traceback entry in ~1e5 came out wrong, run to run (DESIGN 4.4);
   (ii)  the headline kernels have no scratch (private segment): a spill there is a slow-down nobody would notice in a test;
   (iii) the VGPR counts stay inside the occupancy each kernel's geometry assumes.
 The checker itself is tested on a throw-away kernel compiled here with the wait left out (it must be flagged)."""

@@ -94,7 +94,7 @@ def test_gpu_matches_reference_on_real_speech(real, tmp_path, pname, kernel):
                 assert np.array_equal(cost, z[f"{key}_align_full_cost"]) and np.array_equal(cost2, z[f"{key}_align_pruned_cost"])
             else:
                 # GEMM-form scores lose digits where a density has a tiny variance (cancellation ~ mu^2 / sigma^2 * eps,
-                # DESIGN.md 4.1); trained real models have such densities: 2.3e-9 observed, north_star allows 1e-4
+                # DESIGN.md 2); trained real models have such densities: 2.3e-9 observed, north_star allows 1e-4
                 np.testing.assert_allclose(cost, z[f"{key}_align_full_cost"], rtol=1e-6)
                 np.testing.assert_allclose(cost2, z[f"{key}_align_pruned_cost"], rtol=1e-6)
         corpus.close()
