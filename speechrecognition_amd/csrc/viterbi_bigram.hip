@@ -154,17 +154,20 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
   uint32_t r_n[KSR], r_st[KSR][(NPR + 1) / 2], r_bp[KSR][NPR], rc_bp[KSR];  // r_st: two 16-bit state ids per register
   float r_sc[KSR][NPR], rc_sc[KSR];
   bool r_sil[KSR];
-  const uint32_t wave = tid >> 6, lane = tid & 63;
+  const uint32_t lane = tid & 63;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // a SCALAR: the piece loop below runs on the scalar unit
   const uint32_t row_bytes = a.ld * 8u;
   const uint32_t sil_st = REGS ? (a.pos_info[a.slot_off[sil]] & 0xFFFFu) * 8u : 0u;  // row offset of the silence state (every copy's state)
   auto issue_row = [&](uint64_t frame /* 1-based */) {  // every wave copies its share of the row's 1 KB pieces (LDS-DMA: no registers)
-    const unsigned char* src = reinterpret_cast<const unsigned char*>(dense + (frame - 1) * a.ld);
-    for (uint32_t piece = wave; piece * 1024u < row_bytes; piece += kBgWaves) {
-      const uint32_t off = piece * 1024u + lane * 16u;
-      if (off < row_bytes)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
-                                         (__attribute__((address_space(3))) void*)(row_lds + piece * 1024u), 16, 0, 0);
-    }
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(dense + (frame - 1) * a.ld) + lane * 16u;
+    const uint32_t n_full = row_bytes >> 10;
+    uint32_t piece = wave;  // (round 4: with the wave index in a vector register this was an exec-masked vector loop, 18 instructions per piece)
+    for (; piece < n_full; piece += kBgWaves)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024u),
+                                       (__attribute__((address_space(3))) void*)(row_lds + piece * 1024u), 16, 0, 0);
+    if (piece == n_full && lane * 16u < (row_bytes & 1023u))  // (a row is a multiple of 64 bytes: the last piece may be short)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024u),
+                                       (__attribute__((address_space(3))) void*)(row_lds + piece * 1024u), 16, 0, 0);
   };
   if (REGS) {
     for (uint32_t i = tid; i < W; i += kBgThreads) {

@@ -67,7 +67,8 @@ template <int NT, int SPT, bool ROWS>
 __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr uint32_t PP = NT * SPT;
-  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const uint32_t tid = threadIdx.x, lane = tid & 63;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // a SCALAR (see viterbi_words.hip: the piece loop below)
   // smem: [PP] hypothesis cells of 16 bytes, then:
   double* c_best = reinterpret_cast<double*>(smem + (size_t)PP * 16);  // [2] block minimum of the frame's new scores, by frame parity
   double* c_we = c_best + 2;                                        // [2] minimum over word-end slots
@@ -138,12 +139,14 @@ __global__ __launch_bounds__(NT) void decode_fast_kernel(DecodeArgs a) {
   auto issue_row = [&](uint32_t frame /* 1-based */) {  // row of `frame` -> buffer frame & 1; every wave copies its share of the pieces
     const unsigned char* src = reinterpret_cast<const unsigned char*>(row0 + (uint64_t)(frame - 1) * a.ld);
     unsigned char* dst = rows_lds + (frame & 1u) * row_pad;
-    for (uint32_t piece = wave; piece * 1024u < row_bytes; piece += NT / 64) {
-      const uint32_t off = piece * 1024u + lane * 16u;
-      if (off < row_bytes)  // (a row is a multiple of 64 bytes; the last piece may be short)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
-                                         (__attribute__((address_space(3))) void*)(dst + piece * 1024u), 16, 0, 0);
-    }
+    const uint32_t n_full = row_bytes >> 10;
+    uint32_t piece = wave;  // (scalar loop; viterbi_words.hip)
+    for (; piece < n_full; piece += NT / 64)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024u + lane * 16u),
+                                       (__attribute__((address_space(3))) void*)(dst + piece * 1024u), 16, 0, 0);
+    if (piece == n_full && lane * 16u < (row_bytes & 1023u))  // (a row is a multiple of 64 bytes: the last piece may be short)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024u + lane * 16u),
+                                       (__attribute__((address_space(3))) void*)(dst + piece * 1024u), 16, 0, 0);
   };
   double am_c[SPT], am0_c[SPT];
 #pragma unroll

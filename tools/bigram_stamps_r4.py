@@ -1,5 +1,5 @@
-"""Diagnostic: per-step cycles per frame of bigram_kernel, thread 0 of every workgroup (needs the stamps variant of the library:
-/tmp/mk_bg_stamps.py during round 3; the stamps overwrite the traceback scores, so the words are garbage)."""
+"""Diagnostic: per-step s_memtime ticks per frame of bigram_kernel (register layout), thread 0 of every workgroup (needs the stamps variant of
+the library, tools/make_bigram_stamps_variant.py; the stamps overwrite the output scores, so the words are garbage)."""
 import os, sys, tempfile
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
@@ -21,10 +21,12 @@ bg = m.bigram(word_off, mixtures, lex.silence_idx, lm, tdp)
 c = m.upload(feats, off)
 for _ in range(2):
     ow, osc, ot, o = c.recognize_bigram(bg, 200.0, capi.FLT_MAX, capi.GMM_MFMA)
-names = ["U bound", "recombination + best start", "activation", "3 read+compute", "3 barrier", "3 write + reset + wg_min", "4 prune (dense)", "4 compaction", "5 merge", "6 book"]
-acc = np.zeros(10)
+names = ["list read + U bound (wg_min)", "1a silence-copy entries, skip test, keep scan", "1b staging + LM rows + entries + best start (wg_min)", "2 activation (scan, list appends)",
+         "3 expand + emission (registers)", "3 wg_min best score", "4 prune (registers) + flags + barrier", "4 compaction (scan, list writes, barrier)",
+         "5 positions + barrier", "5-6 merge + book entries", "final barrier"]
+acc = np.zeros(11)
 for u in range(len(off) - 1):
     a = int(o[u])
-    acc += osc[a + 1:a + 11]
+    acc += osc[a + 1:a + 12]
 acc /= (len(off) - 1)
 print({n: int(v) for n, v in zip(names, acc)}, "total", int(acc.sum()))
