@@ -64,7 +64,8 @@ __device__ inline uint32_t wave_incl_scan(uint32_t v, int /*lane*/) {
 // ONE barrier: every wave scans the kBgWaves wave totals itself (round 2: a third barrier around a serial loop of thread 0
 // over the 16 totals, ~2 000 cycles, five times a frame).
 __device__ inline uint32_t wg_excl_scan(uint32_t v, uint32_t* tmp, uint32_t* total) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (a scalar: v_readlane below instead of a ds_bpermute round trip)
   const uint32_t inc = wave_incl_scan(v, lane);
   // (no barrier before the write: every call site has a workgroup barrier between the previous scan's reads of `tmp` -- they
   // follow its barrier at once -- and this one)
@@ -73,18 +74,32 @@ __device__ inline uint32_t wg_excl_scan(uint32_t v, uint32_t* tmp, uint32_t* tot
   const uint32_t wt = lane < kBgWaves ? tmp[lane] : 0u;
   const uint32_t winc = wave_incl_scan(wt, lane);  // lanes 0 .. kBgWaves-1: inclusive prefix of the wave totals
   *total = (uint32_t)__builtin_amdgcn_readlane((int)winc, kBgWaves - 1);
-  const uint32_t before = (uint32_t)__shfl((int)(winc - wt), wave);  // exclusive prefix of this wave (wave-uniform index)
+  const uint32_t before = (uint32_t)__builtin_amdgcn_readlane((int)(winc - wt), wave);  // exclusive prefix of this wave
   return before + inc - v;
 }
 
+// minimum over the workgroup (fminf semantics: a NaN loses), returned to every thread; one barrier.  Round 4: the wave and row
+// reductions through DPP (ten vector instructions) instead of ten __shfl_xor = ten dependent ds_bpermute round trips -- about
+// 1 200 of the 3 400-3 700 cycles each of the three calls per frame cost (tools/bigram_stamps_r4.py, profiles/r4_bigram_steps.txt).
+template <int CTRL, int ROW_MASK>
+__device__ inline float dpp_f(float v) {  // lanes without a source keep v
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ inline float wg_min(float v, float* tmp) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-  if ((threadIdx.x & 63) == 0) tmp[threadIdx.x >> 6] = v;  // (as in wg_excl_scan: a barrier lies between two uses of `tmp`)
+  v = fminf(v, dpp_f<0xB1, 0xF>(v));    // quad_perm [1,0,3,2]
+  v = fminf(v, dpp_f<0x4E, 0xF>(v));    // quad_perm [2,3,0,1]
+  v = fminf(v, dpp_f<0x141, 0xF>(v));   // row_half_mirror
+  v = fminf(v, dpp_f<0x140, 0xF>(v));   // row_mirror: every lane holds its row's minimum
+  v = fminf(v, dpp_f<0x142, 0xA>(v));   // row_bcast15 -> rows 1, 3
+  v = fminf(v, dpp_f<0x143, 0xC>(v));   // row_bcast31 -> rows 2, 3: lane 63 holds the wave's minimum
+  if ((threadIdx.x & 63) == 63) tmp[threadIdx.x >> 6] = v;  // (as in wg_excl_scan: a barrier lies between two uses of `tmp`)
   __syncthreads();
   float r = tmp[threadIdx.x & (kBgWaves - 1)];  // one read; the 16 partials sit in every row of 16 lanes
-#pragma unroll
-  for (int o = kBgWaves / 2; o > 0; o >>= 1) r = fminf(r, __shfl_xor(r, o));
+  static_assert(kBgWaves == 16, "the cross-wave stage is a reduction over one row of 16 lanes");
+  r = fminf(r, dpp_f<0xB1, 0xF>(r));
+  r = fminf(r, dpp_f<0x4E, 0xF>(r));
+  r = fminf(r, dpp_f<0x141, 0xF>(r));
+  r = fminf(r, dpp_f<0x140, 0xF>(r));
   return r;
 }
 
@@ -214,6 +229,12 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
   bool overflow = false;
   const __amdgpu_buffer_rsrc_t info_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.pos_info), 0, (int)(P2 * 4u), 0x00020000);
   const __amdgpu_buffer_rsrc_t slot_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.pos_slot), 0, (int)(P2 * 4u), 0x00020000);
+  // The merged word-end list of the previous frame, the thread's own entries [tid * ce, (tid + 1) * ce): in the register layout step 6
+  // hands them over in these registers (round 4: the thread that writes an entry is the thread that reads it next frame -- step 6 used
+  // to walk the list strided, step 1 read it back from HBM, a dependent round trip of ~2 000 cycles at the top of every frame);
+  // the copies in HBM are still written, for the final traceback.
+  uint32_t m_raw[KW], m_bp[KW];
+  float m_sc[KW];
   for (uint64_t t = 1; t <= T; t++) {
     // ---- 1 bigramRecombination + LM beam ------------------------------------------------------------------------
     for (uint32_t i = W + tid; i < W2; i += kBgThreads) en_score[i] = __builtin_inff();
@@ -231,15 +252,15 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
     // registers: one global round trip (~2 000 cycles) instead of five.
     const uint32_t ce1 = (n_we + kBgThreads - 1) / kBgThreads;
     const uint32_t e1_lo = tid * ce1 < n_we ? tid * ce1 : n_we, e1_hi = (e1_lo + ce1 < n_we) ? e1_lo + ce1 : n_we;
-    uint32_t m_raw[KW], m_bp[KW];
-    float m_sc[KW];
+    if (!REGS || t == 1) {  // (register layout: frames 2.. got them from step 6)
 #pragma unroll
-    for (int i = 0; i < KW; i++) {
-      const uint32_t e = e1_lo + (uint32_t)i;
-      const bool in = e < e1_hi;
-      m_raw[i] = in ? we_slot[cur][e] : 0u;
-      m_sc[i] = in ? we_score[cur][e] : 0.0f;
-      m_bp[i] = in ? we_bp[cur][e] : 0u;
+      for (int i = 0; i < KW; i++) {
+        const uint32_t e = e1_lo + (uint32_t)i;
+        const bool in = e < e1_hi;
+        m_raw[i] = in ? we_slot[cur][e] : 0u;
+        m_sc[i] = in ? we_score[cur][e] : 0.0f;
+        m_bp[i] = in ? we_bp[cur][e] : 0u;
+      }
     }
     float lu = kFltMax;
 #pragma unroll
@@ -650,7 +671,13 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
       n_hist = tot_ends - *n_pairs;  // #histories = #word ends - #histories with two of them (counted by their owners in step 4)
       // ---- 6 addBookKeepingEntries for the kept word ends e = 0 .. n_hist-1, in list order ---------------------------
       if ((uint64_t)n_book + n_hist > book_cap) { overflow = true; break; }  // workgroup-uniform
-      for (uint32_t e = tid; e < n_hist; e += kBgThreads) {
+      // thread k owns the contiguous entries [k * ce6, (k + 1) * ce6): the ones step 1 of the next frame gives it (n_hist = the next n_we)
+      const uint32_t ce6 = (n_hist + kBgThreads - 1) / kBgThreads;
+      const uint32_t e6_lo = tid * ce6 < n_hist ? tid * ce6 : n_hist, e6_hi = (e6_lo + ce6 < n_hist) ? e6_lo + ce6 : n_hist;
+#pragma unroll
+      for (int i = 0; i < KW; i++) {
+        const uint32_t e = e6_lo + (uint32_t)i;
+        if (!(e < e6_hi)) { m_raw[i] = 0u; m_sc[i] = 0.0f; m_bp[i] = 0u; continue; }
         uint32_t fi, la;
         first_last(map_copy(pm_slot[e]), &fi, &la);
         uint32_t src = e, mark = 0;
@@ -672,6 +699,7 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
         const uint32_t nb = n_book + e;
         book[nb] = make_uint4(ac_word(sl), __float_as_uint(sc), bp, (uint32_t)t);
         we_slot[cur][e] = sl | mark; we_score[cur][e] = sc; we_bp[cur][e] = nb;
+        m_raw[i] = sl | mark; m_sc[i] = sc; m_bp[i] = nb;
       }
     } else {
       uint32_t* first = reinterpret_cast<uint32_t*>(en_score);  // [W] (entries are consumed; rebuilt next frame)
