@@ -81,25 +81,33 @@ __device__ inline uint32_t wg_excl_scan(uint32_t v, uint32_t* tmp, uint32_t* tot
 // minimum over the workgroup (fminf semantics: a NaN loses), returned to every thread; one barrier.  Round 4: the wave and row
 // reductions through DPP (ten vector instructions) instead of ten __shfl_xor = ten dependent ds_bpermute round trips -- about
 // 1 200 of the 3 400-3 700 cycles each of the three calls per frame cost (tools/bigram_stamps_r4.py, profiles/r4_bigram_steps.txt).
+// v_min_f32 directly.  fminf() canonicalises both operands first (a v_max_f32 x, x each: three instructions per minimum, 68 in the
+// kernel); the hardware minimum already returns the other operand for a (quiet) NaN, and every operand here is the result of an
+// addition or a copy of one, never a signalling NaN.
+__device__ inline float fmin_raw(float a, float b) {
+  float r;
+  asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 template <int CTRL, int ROW_MASK>
 __device__ inline float dpp_f(float v) {  // lanes without a source keep v
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
 }
 __device__ inline float wg_min(float v, float* tmp) {
-  v = fminf(v, dpp_f<0xB1, 0xF>(v));    // quad_perm [1,0,3,2]
-  v = fminf(v, dpp_f<0x4E, 0xF>(v));    // quad_perm [2,3,0,1]
-  v = fminf(v, dpp_f<0x141, 0xF>(v));   // row_half_mirror
-  v = fminf(v, dpp_f<0x140, 0xF>(v));   // row_mirror: every lane holds its row's minimum
-  v = fminf(v, dpp_f<0x142, 0xA>(v));   // row_bcast15 -> rows 1, 3
-  v = fminf(v, dpp_f<0x143, 0xC>(v));   // row_bcast31 -> rows 2, 3: lane 63 holds the wave's minimum
+  v = fmin_raw(v, dpp_f<0xB1, 0xF>(v));    // quad_perm [1,0,3,2]
+  v = fmin_raw(v, dpp_f<0x4E, 0xF>(v));    // quad_perm [2,3,0,1]
+  v = fmin_raw(v, dpp_f<0x141, 0xF>(v));   // row_half_mirror
+  v = fmin_raw(v, dpp_f<0x140, 0xF>(v));   // row_mirror: every lane holds its row's minimum
+  v = fmin_raw(v, dpp_f<0x142, 0xA>(v));   // row_bcast15 -> rows 1, 3
+  v = fmin_raw(v, dpp_f<0x143, 0xC>(v));   // row_bcast31 -> rows 2, 3: lane 63 holds the wave's minimum
   if ((threadIdx.x & 63) == 63) tmp[threadIdx.x >> 6] = v;  // (as in wg_excl_scan: a barrier lies between two uses of `tmp`)
   __syncthreads();
   float r = tmp[threadIdx.x & (kBgWaves - 1)];  // one read; the 16 partials sit in every row of 16 lanes
   static_assert(kBgWaves == 16, "the cross-wave stage is a reduction over one row of 16 lanes");
-  r = fminf(r, dpp_f<0xB1, 0xF>(r));
-  r = fminf(r, dpp_f<0x4E, 0xF>(r));
-  r = fminf(r, dpp_f<0x141, 0xF>(r));
-  r = fminf(r, dpp_f<0x140, 0xF>(r));
+  r = fmin_raw(r, dpp_f<0xB1, 0xF>(r));
+  r = fmin_raw(r, dpp_f<0x4E, 0xF>(r));
+  r = fmin_raw(r, dpp_f<0x141, 0xF>(r));
+  r = fmin_raw(r, dpp_f<0x140, 0xF>(r));
   return r;
 }
 
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
     float lu = kFltMax;
 #pragma unroll
     for (int i = 0; i < KW; i++)
-      if (e1_lo + (uint32_t)i < e1_hi) lu = fminf(lu, m_sc[i] + rowmax(map_copy(m_raw[i] & kSlotMask)));
+      if (e1_lo + (uint32_t)i < e1_hi) lu = fmin_raw(lu, m_sc[i] + rowmax(map_copy(m_raw[i] & kSlotMask)));
     const float U = wg_min(lu, red_tmp);
     // staging buffer: the dedicated 256 entries, or -- for a big lexicon -- the idle half of the active-list double
     // buffer (it is rewritten from scratch in step 4), up to one entry per thread: fewer passes and barriers
@@ -352,13 +360,13 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
       if (w < W && w != sil) {
         en_score[w] = my_score[k];
         en_bp[w] = my_bp[k];
-        lmin = fminf(lmin, my_score[k]);
+        lmin = fmin_raw(lmin, my_score[k]);
       }
     }
     // (no barrier here either: the copies' entries and en_score[sil] read next were written before the scan's barrier above; the
     // words' entries just written are first read in step 2, behind the barrier inside wg_min)
-    for (uint32_t i = W + tid; i < W2; i += kBgThreads) lmin = fminf(lmin, en_score[i]);
-    if (tid == 0) lmin = fminf(lmin, en_score[sil]);
+    for (uint32_t i = W + tid; i < W2; i += kBgThreads) lmin = fmin_raw(lmin, en_score[i]);
+    if (tid == 0) lmin = fmin_raw(lmin, en_score[sil]);
     const float best_start = wg_min(lmin, red_tmp);
     float lm_thr = a.lm_pruning;
     if (lm_thr < kFltMax) lm_thr += best_start;
@@ -455,7 +463,7 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
           if (!in) best = inf;
           if (best < inf) {
             best += pem[p];
-            lbest = fminf(lbest, best);
+            lbest = fmin_raw(lbest, best);
           }
           r_sc[k][p] = best;
           r_bp[k][p] = best < inf ? bb : 0u;
@@ -470,7 +478,7 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
         { const float o = rc_sc[k], c = o + a.tdp[1][0]; if (o < inf && !(best < c)) { best = c; bb = rc_bp[k]; } }
         if (best < inf) {
           best += pem_sil;
-          lbest = fminf(lbest, best);
+          lbest = fmin_raw(lbest, best);
         }
         rc_sc[k] = best;
         rc_bp[k] = best < inf ? bb : 0u;
@@ -536,7 +544,7 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
         { const float c = o1 + t0; if (o1 < inf && !(best < c)) { best = c; src = j; } }
         if (best < inf) {
           best += pem[q];
-          lbest = fminf(lbest, best);
+          lbest = fmin_raw(lbest, best);
         }
         nsc[k] = best;
         srcs[r] = src;
