@@ -343,6 +343,12 @@ def test_cfg5_model_size(tmp_path, oracle_lib):
         wa, oa = corpus.recognize(lexh, 200.0, 10.0, capi.GMM_MFMA)
         wb, ob = corpus.recognize(lexh, 200.0, 10.0, capi.GMM_EXACT)
         assert np.array_equal(wa, wb) and np.array_equal(oa, ob) and len(wa) > 0
+        # round 4: the two-chunk refinement (one evaluation per state, list batches through atomic minima) at this size: every
+        # score of the batch against the exact kernel, bit for bit, and the short utterance against the oracle
+        assert np.array_equal(m.score_frames(short, capi.GMM_PREFILTER).view(np.uint64), want_scores.view(np.uint64))
+        assert np.array_equal(corpus.score(capi.GMM_PREFILTER).view(np.uint64), corpus.score(capi.GMM_EXACT).view(np.uint64))
+        wc, oc = corpus.recognize(lexh, 200.0, 10.0, capi.GMM_DEFAULT)
+        assert np.array_equal(wc, wb) and np.array_equal(oc, ob)
         corpus.close()
         lexh.close()
 
