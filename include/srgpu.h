@@ -52,7 +52,8 @@ SR_API int sr_abi_version(void);
                            lexicon): no words are reported for the call */
 
 /* GMM scoring kernels (MixtureModel::score, Mixtures.cpp:737-744) */
-#define SR_GMM_MFMA 0   /* FP64 MFMA contraction + fused min / log-sum epilogue (default; ~1e-15 rel.) */
+#define SR_GMM_MFMA 0   /* dense FP64 MFMA contraction + fused min / -log-sum-exp epilogue (<= 1e-9 relative, ~1e-15 on
+                           well-conditioned models; what SR_GMM_DEFAULT picks for sum scoring) */
 #define SR_GMM_EXACT 1  /* direct form replaying density_score_sse's operation order (Mixtures.cpp:645-690): bit-exact */
 #define SR_GMM_PREFILTER 2  /* bit-exact like SR_GMM_EXACT: a 16-bit MFMA prefilter selects the densities that can be the
                                minimum, FP64 replays only those.  Max-approx models with <= 128 densities per mixture and

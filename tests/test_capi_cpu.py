@@ -145,3 +145,14 @@ def test_shard_utterances_matches_the_python_helper(built_lib):
             assert int(load[r]) == int(lens[want[r]].sum()) if n_utts else int(load[r]) == 0
     with pytest.raises(capi.SrError):
         capi.shard_utterances(np.array([0, 5], np.uint64), 0)
+
+
+def test_abi_version_matches_the_header_and_the_binding(built_lib):
+    """a struct of the ABI grew without a version to tell callers.  The header's SR_ABI_VERSION, the library's
+    sr_abi_version() and the ctypes binding's constant are one number; capi.lib() refuses a library that disagrees."""
+    from speechrecognition_amd import capi
+    hdr = open(os.path.join(ROOT, "include", "srgpu.h")).read()
+    want = int(re.search(r"#define\s+SR_ABI_VERSION\s+(\d+)", hdr).group(1))
+    L = ctypes.CDLL(built_lib)
+    assert L.sr_abi_version() == want == capi.SR_ABI_VERSION
+    assert capi.lib().sr_abi_version() == want
