@@ -21,7 +21,9 @@ def run_case(case, seed0=0, ragged=False, tmp=None):
     rng = np.random.default_rng(seed0 * 100003 + case)
     W = int(rng.choice([2, 5, 17, 60, 300]))
     if ragged == "short" and rng.random() < 0.15:
-        W = int(rng.choice([1100, 2300]))  # two and three words per lane
+        # two and three words per lane; 2900 three- and four-position words: more than 8192 type-padded positions, the word-per-lane
+        # kernel with decode_big_kernel as its replay (round 4)
+        W = int(rng.choice([1100, 2300, 2900]))
     spw = int(rng.integers(1, 5))
     reps = int(rng.integers(1, 3))
     if spw * reps < 2:
@@ -105,6 +107,19 @@ def run_case(case, seed0=0, ragged=False, tmp=None):
         lexh.close()
         corpus.close()
     o.close()
+    # sum scoring (max-approx false, Mixtures.cpp:719-728) through SR_GMM_DEFAULT = the FP64-MFMA kernel (round 4) and through the
+    # direct-form kernel: 1e-9 / 1e-12 of the oracle (device exp / log); on the small cases only (the oracle's dense sum-mode matrix)
+    if lex.n_states * int(off[-1]) <= 400000 and D <= 46:
+        o = pyoracle.Oracle(mp, D, lex, am_threshold=beam, max_approx=False)
+        want_sum = o.score_matrix(feats)
+        o.close()
+        with capi.Model.from_mixset(mp, D, max_approx=False) as m:
+            for k, tol in ((capi.GMM_DEFAULT, 1e-9), (capi.GMM_EXACT, 1e-12)):
+                got = m.score_frames(feats, k)
+                fin = np.isfinite(want_sum)
+                assert np.array_equal(np.isfinite(got), fin), (tag, "sum mode finiteness", k)
+                err = np.abs(got[fin] - want_sum[fin]) / np.maximum(np.abs(want_sum[fin]), 1.0)
+                assert err.max(initial=0.0) <= tol, (tag, "sum mode", k, float(err.max(initial=0.0)))
     return tag
 
 
@@ -121,7 +136,7 @@ def ledger_line(seed0, generator, n_cases, done, failure, secs):
             "first_failure": failure, "wall_s": round(secs, 1), "git_head": info.get("git_head", "unknown") + ("+dirty" if info.get("dirty") else ""),
             "kernel_sources_sha16": h.hexdigest()[:16], "library": os.environ.get("SRGPU_LIB", "in-tree libsrgpu.so"),
             "checks": "scores prefilter+exact == oracle (uint64); words, traceback, full+pruned alignments == oracle; word-per-lane == slot kernel; "
-                      "bigram register layout == dense layout == oracle restatement"}
+                      "bigram register layout == dense layout == oracle restatement; sum mode (SR_GMM_DEFAULT 1e-9, exact kernel 1e-12) on the small cases"}
 
 
 if __name__ == "__main__":
