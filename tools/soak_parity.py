@@ -95,8 +95,13 @@ def run_case(case, seed0=0, ragged=False, tmp=None):
             lmp = float(rng.choice([5.0, 25.0, pyoracle.FLT_MAX]))
             bg = m.bigram(word_off, automaton, lex.silence_idx, lm, tdp)
             gw, gs, gt, goff = corpus.recognize_bigram(bg, acp, lmp)
-            dw, ds, dt, doff = corpus.recognize_bigram(bg, acp, lmp, dense_states=True)  # register layout (short words) vs dense LDS image
-            assert np.array_equal(gw, dw) and np.array_equal(gt, dt) and np.array_equal(goff, doff) and np.array_equal(gs.view(np.uint32), ds.view(np.uint32)), (tag, "bigram layouts")
+            try:
+                dw, ds, dt, doff = corpus.recognize_bigram(bg, acp, lmp, dense_states=True)  # register layout (short words) vs dense LDS image
+            except capi.SrError as e:
+                if e.code != -4:  # SR_ELIMIT: a lexicon whose dense image does not fit the LDS runs in the register layout only
+                    raise
+            else:
+                assert np.array_equal(gw, dw) and np.array_equal(gt, dt) and np.array_equal(goff, doff) and np.array_equal(gs.view(np.uint32), ds.view(np.uint32)), (tag, "bigram layouts")
             for u in range(n_utts):
                 x = feats[int(off[u]):int(off[u + 1])]
                 w, s_, t_ = pyoracle.bigram_decode(want[int(off[u]):int(off[u + 1])], word_off, automaton, lex.silence_idx, lm, tdp, acp, lmp)
@@ -155,8 +160,8 @@ if __name__ == "__main__":
             tag = run_case(case, seed0, ragged, tmp)
             done += 1
             print(f"ok {tag}  [{time.time() - t_start:.0f} s]", flush=True)
-    except AssertionError as e:
-        failure = {"case": done, "what": str(e)[:400]}
+    except Exception as e:  # a mismatch (AssertionError) or an error status of the library
+        failure = {"case": done, "what": f"{type(e).__name__}: {e}"[:400]}
         raise
     finally:
         if ledger:
