@@ -178,6 +178,7 @@ struct sr_lexicon {
 struct sr_bigram {
   sr_model* model = nullptr;
   uint32_t n_words = 0, silence = 0, n_positions = 0, max_slot_states = 0, silence_states = 0;
+  uint32_t row4_mask = 0;  // bit k: some word of slot row k (words k * 1024 .. k * 1024 + 1023) has four states (register layout)
   float tdp[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   DevBuf<uint32_t> slot_off, slot_mix;
   DevBuf<uint16_t> mixtures;

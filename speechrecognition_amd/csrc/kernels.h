@@ -214,6 +214,7 @@ struct BigramArgs {
   uint32_t max_slot_states;     // most states of any slot
   uint32_t silence_states;      // states of the silence word (= of every silence copy)
   uint32_t dense_states;        // keep the state hypotheses in the dense LDS image even where the register layout applies
+  uint32_t row4_mask;           // register layout: bit k = slot row k (words k * 1024 ...) holds a word of four states (the other rows keep three)
 };
 hipError_t launch_bigram(const BigramArgs& a, hipStream_t stream);
 size_t bigram_lds_bytes(uint32_t n_words, uint32_t n_positions);

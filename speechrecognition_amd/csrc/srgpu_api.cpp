@@ -1219,6 +1219,8 @@ int sr_bigram_create(sr_model* m, uint32_t n_words, const uint32_t* word_off, co
   b->model = m; b->n_words = W; b->silence = silence_word; b->n_positions = P2;
   for (uint32_t a2 = 0; a2 < 2 * W; a2++) b->max_slot_states = std::max(b->max_slot_states, slot_off[a2 + 1] - slot_off[a2]);
   b->silence_states = n_sil;
+  for (uint32_t w = 0; w < W; w++)  // (words only: a silence copy has the silence word's one state in the register layout)
+    if (slot_off[w + 1] - slot_off[w] >= 4) b->row4_mask |= 1u << (w / 1024u);
   memcpy(b->tdp, tdp, sizeof(b->tdp));
   hipError_t e;
   if ((e = b->slot_off.upload(slot_off.data(), slot_off.size())) != hipSuccess ||
@@ -1281,7 +1283,7 @@ int sr_recognize_bigram_corpus(sr_model* m, sr_corpus* c, sr_bigram* b, const sr
   memcpy(ba.tdp, b->tdp, sizeof(ba.tdp));
   ba.ac_pruning = p->acoustic_pruning; ba.lm_pruning = p->lm_pruning;
   if (p->flags & ~SR_BIGRAM_DENSE_STATES) return fail(SR_EINVAL, "unknown sr_bigram_params.flags 0x%x", (unsigned)p->flags);
-  ba.max_slot_states = b->max_slot_states; ba.silence_states = b->silence_states;
+  ba.max_slot_states = b->max_slot_states; ba.silence_states = b->silence_states; ba.row4_mask = b->row4_mask;
   ba.dense_states = (p->flags & SR_BIGRAM_DENSE_STATES) ? 1u : 0u;
   if (!bigram_register_layout(ba) && bigram_lds_bytes(W, b->n_positions) > 160 * 1024)
     return fail(SR_ELIMIT, "this lexicon runs in the register layout only (its dense LDS image would take %zu bytes > 160 KiB)", bigram_lds_bytes(W, b->n_positions));

@@ -120,9 +120,14 @@ __device__ inline float wg_min(float v, float* tmp) {
 //            states read" barrier, no atomics for the survivor flags; the frame's emission costs are staged in LDS by LDS-DMA
 //            (one row buffer, fetched while steps 4-6 and 1-2 of the next frame run).  The final state of a surviving word end is
 //            published through the entry arrays, which are dead between step 3 and step 5.
-template <int KW, int KP, int KS, int NP>  // KW words per thread in the recombination: W <= KW * kBgThreads
+// NPM (register layout): 0 = every word has at most three states; else bit k = slot row k (the words k * 1024 .. k * 1024 + 1023) holds a
+// word of four states -- only those rows carry the fourth state's registers and arithmetic (round 4; configs[4]'s lexicon has ONE
+// four-state word, in row 2: rows 0 and 1 are three-state rows).
+template <int KW, int KP, int KS, int NPM>  // KW words per thread in the recombination: W <= KW * kBgThreads
 __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
   constexpr bool REGS = KS > 0;
+  constexpr int NP = NPM ? 4 : 3;  // states a lane keeps per word at most
+  auto np_of = [](int k) constexpr { return ((NPM >> k) & 1) ? 4 : 3; };  // ... and in slot row k
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t W = a.n_words, W2 = 2 * a.n_words, P2 = REGS ? 0u : a.n_positions, sil = a.silence;
   float* st_score = reinterpret_cast<float*>(smem);           // [P2]   (dense layout only)
@@ -442,14 +447,18 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
       for (int k = 0; k < KS; k++) {
         const uint32_t w = tid + (uint32_t)k * kBgThreads;
         const bool sil_ = r_sil[k];
-        const float t0 = sil_ ? a.tdp[1][0] : a.tdp[0][0], t1 = sil_ ? a.tdp[1][1] : a.tdp[0][1], t2 = sil_ ? a.tdp[1][2] : a.tdp[0][2];
+        // the silence word has ONE state in this layout (bigram_register_layout): of its penalties only the loop applies -- forward
+        // and skip into states it does not have are computed and discarded (`in` below) -- so the words' are scalars for every lane
+        const float t0 = sil_ ? a.tdp[1][0] : a.tdp[0][0], t1 = a.tdp[0][1], t2 = a.tdp[0][2];
         const float ent = w < W ? en_score[w] : inf;
         const uint32_t ebp = w < W ? en_bp[w] : 0u;
         float pem[NP];
 #pragma unroll
-        for (int p = 0; p < NP; p++) pem[p] = (float)*reinterpret_cast<const double*>(row_lds + ((r_st[k][p / 2] >> (16 * (p & 1))) & 0xFFFFu) * 8u);
+        for (int p = 0; p < NP; p++)
+          if (p < np_of(k)) pem[p] = (float)*reinterpret_cast<const double*>(row_lds + ((r_st[k][p / 2] >> (16 * (p & 1))) & 0xFFFFu) * 8u);
 #pragma unroll
         for (int p = NP - 1; p >= 0; p--) {
+          if (p >= np_of(k)) continue;  // (compile time: this row has no fourth state)
           const bool in = (uint32_t)p < r_n[k];
           float best = inf;
           uint32_t bb = 0;
@@ -529,7 +538,9 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
         const uint32_t j = tid + (uint32_t)k * kBgThreads;
         const uint32_t fl = pinfo[q] >> 16, sl = pslot[q];
         const bool sil_ = (fl >> 3) & 1u, in = j < P2;
-        const float t0 = sil_ ? a.tdp[1][0] : a.tdp[0][0], t1 = sil_ ? a.tdp[1][1] : a.tdp[0][1], t2 = sil_ ? a.tdp[1][2] : a.tdp[0][2];
+        // the silence word has ONE state in this layout (bigram_register_layout): of its penalties only the loop applies -- forward
+        // and skip into states it does not have are computed and discarded (`in` below) -- so the words' are scalars for every lane
+        const float t0 = sil_ ? a.tdp[1][0] : a.tdp[0][0], t1 = a.tdp[0][1], t2 = a.tdp[0][2];
         const float inf = __builtin_inff();
         // states 1 and 2 are reachable from the virtual entry state 0: free to state 1, skip penalty to state 2
         const float ent = (in && (fl & 3u)) ? c_ent[r] : inf;
@@ -583,6 +594,7 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
         uint32_t f_bp = 0;
 #pragma unroll
         for (int p = 0; p < NP; p++) {
+          if (p >= np_of(k)) continue;  // (compile time)
           const float v = r_sc[k][p];
           if (v < __builtin_inff()) {
             if (v + pen < ac_thr) {
@@ -804,12 +816,31 @@ hipError_t launch_bigram(const BigramArgs& a, hipStream_t stream) {
     return hipGetLastError();
   };
   const uint32_t kw = (a.n_words + kBgThreads - 1) / kBgThreads, kp = (a.n_positions + kBgThreads - 1) / kBgThreads;
-  if (regs) {  // lane tid: words tid + k * 1024 and their silence copies; three or four states per word
-#define SR_BG_R(KWv) do { if (a.max_slot_states <= 3) return go(bigram_kernel<KWv, 4, KWv, 3>); return go(bigram_kernel<KWv, 4, KWv, 4>); } while (0)
-    if (kw <= 1) SR_BG_R(1);
-    if (kw <= 2) SR_BG_R(2);
-    SR_BG_R(3);
-#undef SR_BG_R
+  if (regs) {  // lane tid: words tid + k * 1024 and their silence copies; three states per word, four in the slot rows of row4_mask
+    const uint32_t mask = a.max_slot_states <= 3 ? 0u : (a.row4_mask ? a.row4_mask : (1u << kw) - 1u);
+    switch (kw <= 1 ? 1 : kw <= 2 ? 2 : 3) {
+      case 1:
+        if (mask == 0) return go(bigram_kernel<1, 4, 1, 0>);
+        return go(bigram_kernel<1, 4, 1, 1>);
+      case 2:
+        switch (mask & 3u) {
+          case 0: return go(bigram_kernel<2, 4, 2, 0>);
+          case 1: return go(bigram_kernel<2, 4, 2, 1>);
+          case 2: return go(bigram_kernel<2, 4, 2, 2>);
+          default: return go(bigram_kernel<2, 4, 2, 3>);
+        }
+      default:
+        switch (mask & 7u) {
+          case 0: return go(bigram_kernel<3, 4, 3, 0>);
+          case 1: return go(bigram_kernel<3, 4, 3, 1>);
+          case 2: return go(bigram_kernel<3, 4, 3, 2>);
+          case 3: return go(bigram_kernel<3, 4, 3, 3>);
+          case 4: return go(bigram_kernel<3, 4, 3, 4>);
+          case 5: return go(bigram_kernel<3, 4, 3, 5>);
+          case 6: return go(bigram_kernel<3, 4, 3, 6>);
+          default: return go(bigram_kernel<3, 4, 3, 7>);
+        }
+    }
   }
 #define SR_BG(KWv, KPv) return go(bigram_kernel<KWv, KPv, 0, 0>)
 #define SR_BG_KP(KWv) do { if (kp <= 4) SR_BG(KWv, 4); if (kp <= 12) SR_BG(KWv, 12); if (kp <= 20) SR_BG(KWv, 20); return hipErrorInvalidValue; } while (0)
