@@ -536,6 +536,22 @@ def test_prefilter_full_size_matches_exact_kernel(tmp_path):
     assert np.array_equal(got.view(np.uint64), exact.view(np.uint64))
 
 
+def test_prefilter_two_chunk_states_at_scale_match_exact_kernel(tmp_path):
+    """BASELINE configs[4]'s model (8000 states x 64 densities = two 32-slot chunks per state): 12 000 frames = 96 M (frame, state)
+    pairs through the prefilter path and the exact kernel, bit for bit.  Round 4's refinement evaluates one candidate per STATE and lets
+    its list batches lower the shared table entry with floating-point atomic minima issued behind the row stores of the same wave: about
+    ten million such atomics here, every one of which must land after the plain store it follows."""
+    lex = synth.make_lexicon(2666, 3, 1, extra_states_last=1)
+    spec = synth.make_mixset(lex.n_states, 64, 39, seed=6)
+    mp = str(tmp_path / "big64.mix")
+    synth.write_mixset(mp, spec)
+    feats, _ = synth.make_batch(40, 200, 400, 39, seed=12)
+    with capi.Model.from_mixset(mp, 39) as m:
+        got = m.score_frames(feats, capi.GMM_PREFILTER)
+        exact = m.score_frames(feats, capi.GMM_EXACT)
+    assert np.array_equal(got.view(np.uint64), exact.view(np.uint64))
+
+
 def test_fp16_matrix_pipe_keeps_subnormals():
     """An assumption of the prefilter's error bound (gmm_prefilter.hip): fp16 subnormal inputs are not flushed.  If this
     ever fails the library falls back to the exact kernel by itself; the test makes the change visible."""
