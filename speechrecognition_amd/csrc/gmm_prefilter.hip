@@ -696,7 +696,8 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
         }
         res[r] = 1e10;  // min_score seed (Mixtures.cpp:699)
         if (nd[r * CH]) {  // wave-uniform (a state without densities keeps the seed; chunk 0 fills first)
-          // lanes of one wave instruction now read up to CH panels: slot d of every panel of a state shares a bank pair
+          // lanes of one wave instruction now read up to CH panels, and slot d of every panel of a state shares a bank pair: 2-way
+          // conflicts that cost nothing measurable (the LDS array is 41 % busy; profiles/r4_refine_chunked.txt, probe 1)
           const double score = evaluate(panel_raw + (size_t)(r * CH) * state_bytes + off + (uint32_t)__builtin_ctz(msel | 0x80000000u) * 8u);
           res[r] = msel != 0 ? seeded_min(score) : res[r];
           if (counting) n_eval += (uint32_t)__builtin_popcountll(__ballot(valid));
@@ -704,7 +705,8 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
 #pragma unroll
         for (int c = 0; c < CH; c++) {
           // what is left for the lists: the selected chunk without its first candidate; every later chunk in full (the
-          // earlier ones are empty).  The batches take the best score so far from the table (shared by the state's chunks).
+          // earlier ones are empty).  The entry carries the state's best score so far; the batches lower the table entry, which
+          // the state's chunks share, with an atomic minimum where their candidate beats it.
           const bool is_sel = off == (uint32_t)c * state_bytes;
           const uint32_t rest = is_sel ? msel & (msel - 1) : mk[r * CH + c];
           if (nd[r * CH + c]) append(r * CH + c, valid && rest != 0, rest, res[r]);

@@ -10,7 +10,7 @@
 // (viterbi_fast.hip) moves through LDS per frame, 16 bytes per hypothesis read up to three times and written once, and the
 // barrier that separates those reads from the writes, do not exist here.  Per frame:
 //
-//   A  every lane: emission costs of its positions from the score row in LDS (staged by LDS-DMA one frame ahead), the new
+//   A  every lane: emission costs of its positions from the score row in LDS (staged by LDS-DMA, issued two frames ahead right behind the barrier), the new
 //      hypotheses from the old ones in registers, in the reference's source order (skip, forward, loop ascending by source
 //      index; a later candidate must be strictly better), the boundary candidate (m_we + word penalty) + tdp + position 0's
 //      emission for positions 0 and 1 (Recognizer.cpp:133-157, :148-151 for the emission quirk);
