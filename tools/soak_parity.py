@@ -155,11 +155,18 @@ if __name__ == "__main__":
     tmp = tempfile.mkdtemp()
     t_start = time.time()
     done, failure = 0, None
+    import signal
+
+    def _stop(signum, frame):  # a run cut by `timeout` still writes its ledger line
+        raise KeyboardInterrupt(f"signal {signum}")
+    signal.signal(signal.SIGTERM, _stop)
     try:
         for case in range(n_cases):
             tag = run_case(case, seed0, ragged, tmp)
             done += 1
             print(f"ok {tag}  [{time.time() - t_start:.0f} s]", flush=True)
+    except KeyboardInterrupt as e:  # cut short from outside (time limit): not a failure, the line says how far it got
+        print(f"stopped after {done} cases ({e})", flush=True)
     except Exception as e:  # a mismatch (AssertionError) or an error status of the library
         failure = {"case": done, "what": f"{type(e).__name__}: {e}"[:400]}
         raise
@@ -167,4 +174,4 @@ if __name__ == "__main__":
         if ledger:
             with open(ledger, "a") as f:
                 f.write(json.dumps(ledger_line(seed0, ragged, n_cases, done, failure, time.time() - t_start)) + "\n")
-    print("soak passed:", n_cases, "cases")
+    print("soak passed:", done, "cases" + ("" if done == n_cases else f" (of {n_cases} asked: stopped by the time limit)"))
