@@ -61,8 +61,11 @@ SR_API int sr_abi_version(void);
 
 #define SR_GMM_DEFAULT 3  /* what a drop-in caller wants: the fastest kernel that reproduces MixtureModel::score for THIS model --
                              SR_GMM_PREFILTER (bit-exact) for max-approx models; for sum scoring (max-approx false,
-                             Mixtures.cpp:719-728) the FP64-MFMA kernel with its fused -log sum exp: device exp / log put every
-                             sum-mode kernel 1e-12 from the reference's libm either way, and the dense direct form is 3x slower.
+                             Mixtures.cpp:719-728) the FP64-MFMA kernel with its fused -log sum exp, i.e. SR_GMM_MFMA's bound:
+                             <= 1e-9 relative (measured 6e-16 on synthetic models, 2.3e-9 worst on a trained real-speech model;
+                             the direct form SR_GMM_EXACT is 1e-12 from the reference's libm in sum mode and 3x slower -- a
+                             caller that wants those three digits passes SR_GMM_EXACT).  Words and tracebacks through this
+                             selector are held to the reference on the sum-mode goldens (tests/test_gpu_parity.py).
                              The aligner / path-score entry points score only the states they need with the bit-exact kernel. */
 
 typedef struct sr_model sr_model;     /* replaces MixtureModel as a FeatureScorer (Mixtures.hpp:18, FeatureScorer.hpp:12-16) */

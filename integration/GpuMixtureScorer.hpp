@@ -12,10 +12,12 @@
 #ifndef __GPU_MIXTURE_SCORER_HPP__
 #define __GPU_MIXTURE_SCORER_HPP__
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "Corpus.hpp"
@@ -29,7 +31,7 @@ public:
   // same arguments as MixtureModel's constructor in recognize mode (Mixtures.cpp:156-174); pooling is
   // MixtureModel::VarianceModel cast to int
   GpuMixtureScorer(std::string const& mixture_path, size_t dimension, int pooling, bool max_approx, int device = 0)
-                  : dimension_(dimension), model_(NULL) {
+                  : dimension_(dimension), model_(NULL), id_(new_id()) {
     if (sr_model_load_mixset(mixture_path.c_str(), dimension, pooling, max_approx, device, &model_) != SR_OK) {
       throw std::runtime_error(sr_last_error());
     }
@@ -69,22 +71,33 @@ private:
     std::vector<double> table;
     Sequence() : start(NULL) {}
   };
-  // the calling thread's slot for THIS scorer (a thread may drive several scorers; the last one used is cached)
+  // The calling thread's slot for THIS scorer.  The slots live in the object (one per thread that ever called
+  // prepare_sequence on it) and go with it; a thread caches the slot of the scorer it used last, keyed by the scorer's
+  // unique id -- not its address: a scorer constructed where a destroyed one stood must not inherit that one's table
+  // (other num_states_ = wrong stride) -- so score(), called once per (frame, state) by the reference's search, takes no
+  // lock.  score() must run on the thread that ran prepare_sequence for the sequence (Recognizer.cpp:104-179 does).
   Sequence& sequence() const {
-    static thread_local std::map<const GpuMixtureScorer*, Sequence> slots;
-    static thread_local const GpuMixtureScorer* last_owner = NULL;
-    static thread_local Sequence*               last       = NULL;
-    if (last_owner != this) {
-      last       = &slots[this];
-      last_owner = this;
+    static thread_local uint64_t  last_id = 0;  // (ids start at 1)
+    static thread_local Sequence* last    = NULL;
+    if (last_id != id_) {
+      std::lock_guard<std::mutex> lock(slots_mutex_);
+      last    = &slots_[std::this_thread::get_id()];  // (map nodes do not move when others are inserted)
+      last_id = id_;
     }
     return *last;
+  }
+  static uint64_t new_id() {
+    static std::atomic<uint64_t> next(0);
+    return ++next;
   }
 
   size_t             dimension_;
   sr_model*          model_;
   uint32_t           num_states_;
+  uint64_t           id_;
   mutable std::mutex device_mutex_;
+  mutable std::mutex slots_mutex_;
+  mutable std::map<std::thread::id, Sequence> slots_;
 };
 
 // Whole-corpus recognition on the device: what Recognizer::recognize's loop body computes per segment

@@ -348,8 +348,8 @@ int prof_end(sr_model* m, hipStream_t s, EventPair* ep) {
 // kernel-specific model packing (first use) and workspaces for scoring launches of up to n_max frames: growing a
 // workspace frees the old one, which must not happen between launches that are still queued
 // SR_GMM_DEFAULT for a dense table: the fastest kernel that gives the reference's results -- the bit-exact prefilter path for
-// max-approx models; for sum scoring (Mixtures.cpp:719-728) the FP64-MFMA kernel with its fused -log sum exp epilogue: the
-// device exp / log put every sum-mode kernel 1e-12 from the reference anyway, and the dense direct form is 3x slower.
+// max-approx models; for sum scoring (Mixtures.cpp:719-728) the FP64-MFMA kernel with its fused -log sum exp epilogue, within
+// SR_GMM_MFMA's 1e-9 (the direct form stays 1e-12 from the reference's libm in sum mode, at 3x the time: SR_GMM_EXACT on request).
 int resolve_dense_kernel(const sr_model* m, int gmm_kernel) {
   return gmm_kernel != SR_GMM_DEFAULT ? gmm_kernel : m->max_approx ? SR_GMM_PREFILTER : SR_GMM_MFMA;
 }

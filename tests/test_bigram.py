@@ -141,7 +141,10 @@ def linear_search_py(dense, word_off, mixtures, silence, lm, tdp, ac_pruning=FLT
     return [r[0] for r in res], [r[1] for r in res], [r[3] for r in res]
 
 
-def _setup(tmp_path, seed, W, spw, M=3, D=12, sil_states=1, reps=1):
+SIL_TDP = np.array([[3.0, 0.0, 30.0, 5.0], [1.0, 7.0, 3.0, 2.0]], np.float32)  # silence forward / skip clearly unlike the words'
+
+
+def _setup(tmp_path, seed, W, spw, M=3, D=12, sil_states=1, reps=1, tdp=None):
     """random model + lexicon (word 0 = silence) + Dirichlet bigram + an utterance sampled along random words"""
     rng = np.random.default_rng(seed)
     lex = synth.make_lexicon(W, spw, reps)
@@ -154,7 +157,8 @@ def _setup(tmp_path, seed, W, spw, M=3, D=12, sil_states=1, reps=1):
     nW = lex.n_words
     p = rng.dirichlet(np.ones(nW), size=nW)          # p[h, w]
     lm = (-np.log(p)).T.astype(np.float32).copy()    # lm[w, h]
-    tdp = np.array([[3.0, 0.0, 30.0, 5.0], [1.0, 0.0, 40.0, 2.0]], np.float32)
+    if tdp is None:
+        tdp = np.array([[3.0, 0.0, 30.0, 5.0], [1.0, 0.0, 40.0, 2.0]], np.float32)
     words = rng.integers(1, nW, size=4)
     feats = synth.sample_utterance(spec, lex, words, seed=seed + 1)
     return lex, spec, mp, word_off, mixtures, lm, tdp, feats
@@ -177,6 +181,26 @@ def test_restatement_matches_python_transcription(tmp_path, oracle_lib, seed, W,
     assert list(w) == pw and list(t) == pt
     assert np.array_equal(np.asarray(s, np.float32).view(np.uint32), np.asarray(ps, np.float32).view(np.uint32))
     assert len(w) > 0
+
+
+@pytest.mark.parametrize("seed,sil_states", [(31, 2), (32, 3), (33, 4)])
+def test_silence_of_several_states_takes_the_silence_penalties(tmp_path, oracle_lib, seed, sil_states):
+    """inside a silence word of more than one state -- and inside its copies -- forward and skip cost
+    tdp[isSilence][1], [2] (LinearSearch.cc:296-326).  The case must DEPEND on them: with the words' penalties in their place the
+    restatement's scores change, so a kernel that mixes the two up cannot pass the GPU twin of this test."""
+    pyoracle = oracle_lib
+    lex, spec, mp, word_off, mixtures, lm, tdp, feats = _setup(tmp_path, seed, 6, 3, sil_states=sil_states, tdp=SIL_TDP)
+    o = pyoracle.Oracle(mp, 12, lex)
+    dense = o.score_matrix(feats)
+    o.close()
+    w, s, t = pyoracle.bigram_decode(dense, word_off, mixtures, lex.silence_idx, lm, tdp, 90.0, 25.0)
+    pw, ps, pt = linear_search_py(dense, word_off, mixtures, lex.silence_idx, lm, tdp, f32(90.0), f32(25.0))
+    assert list(w) == pw and list(t) == pt
+    assert np.array_equal(np.asarray(s, np.float32).view(np.uint32), np.asarray(ps, np.float32).view(np.uint32))
+    wrong = tdp.copy()
+    wrong[1, 1:3] = tdp[0, 1:3]
+    w2, s2, t2 = pyoracle.bigram_decode(dense, word_off, mixtures, lex.silence_idx, lm, wrong, 90.0, 25.0)
+    assert not (list(w2) == list(w) and np.array_equal(np.asarray(s2, np.float32), np.asarray(s, np.float32))), "case does not exercise the silence penalties"
 
 
 def test_restatement_ties_and_merge_quirk(tmp_path, oracle_lib):
@@ -205,12 +229,16 @@ def test_restatement_ties_and_merge_quirk(tmp_path, oracle_lib):
     (16, 300, 3, 150.0, 12.0, 1),     # more words than one pass of the recombination staging buffer
     (17, 1100, 2, 90.0, 8.0, 1),      # more words than threads: two words per thread in the recombination
     (18, 2200, 1, 60.0, 6.0, 1),      # four words per thread, one-state words
+    (31, 6, 3, 90.0, 25.0, 2),        # silence of several states with its own forward / skip penalties (SIL_TDP): the dense layout
+    (32, 6, 3, 90.0, 25.0, 3),
+    (33, 6, 3, 90.0, 25.0, 4),
+    (34, 1200, 3, 120.0, 15.0, 2),    # the same beyond one word per thread
 ])
 def test_gpu_bigram_matches_restatement(tmp_path, oracle_lib, seed, W, spw, acp, lmp, sil_states):
     from speechrecognition_amd import capi
 
     pyoracle = oracle_lib
-    lex, spec, mp, word_off, mixtures, lm, tdp, feats = _setup(tmp_path, seed, W, spw, sil_states=sil_states)
+    lex, spec, mp, word_off, mixtures, lm, tdp, feats = _setup(tmp_path, seed, W, spw, sil_states=sil_states, tdp=SIL_TDP if seed >= 31 else None)
     rng = np.random.default_rng(seed + 5)
     utts = [feats, rng.standard_normal((37, 12)).astype(np.float32), feats[: len(feats) // 2], feats[:1]]
     off = np.concatenate([[0], np.cumsum([len(x) for x in utts])]).astype(np.uint64)

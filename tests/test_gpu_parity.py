@@ -54,10 +54,10 @@ def test_golden_scores(name, tmp_path):
         _assert_scores_close(mfma.reshape(-1)[c.z["score_idx"]], c.z["score_val"])
 
 
-EXACT_KERNELS = (capi.GMM_EXACT, capi.GMM_PREFILTER)
+EXACT_KERNELS = (capi.GMM_EXACT, capi.GMM_PREFILTER, capi.GMM_DEFAULT)  # (DEFAULT: bit-exact for max-approx models; every use below also asks c.max_approx)
 
 
-@pytest.mark.parametrize("kernel", [capi.GMM_EXACT, capi.GMM_PREFILTER, capi.GMM_MFMA])
+@pytest.mark.parametrize("kernel", [capi.GMM_EXACT, capi.GMM_PREFILTER, capi.GMM_MFMA, capi.GMM_DEFAULT])
 @pytest.mark.parametrize("name", golden_names())
 def test_golden_decode_and_align(name, kernel, tmp_path, oracle_lib):
     c = Case(name, tmp_path)

@@ -33,15 +33,28 @@ def objects():
         yield out
 
 
+# the LDS atomics that viterbi_words / viterbi_fast issue from INLINE ASM (dpp_util.h: publish_min*_f64_lds, lds_min5_u32).  Atomics the
+# compiler emits itself (atomicAdd / atomicOr / atomicMin on __shared__, as in viterbi_bigram: ds_add_u32, ds_or_b32, ...) are seen by
+# its own wait-count insertion and need no check; neither of the two objects below has a compiler-generated ds_min_*.
+LDS_ATOMICS = ("ds_min_f64", "ds_min_u32")
+
+
+def _is_lds_atomic(ins):
+    """A no-return LDS atomic (the `_rtn_` forms hand their result to a register the compiler tracks, wait included)."""
+    op = ins.split()[0]
+    return "_rtn_" not in op and op.startswith(LDS_ATOMICS)
+
+
 def unguarded_lds_atomics(insts):
-    """Indices of ds_min_f64 instructions that are NOT followed by `s_waitcnt ... lgkmcnt(0)` before control can reach a barrier
-    or leave the straight line: between the atomic and its wait only further LDS atomics may stand."""
+    """Indices of no-return LDS atomics (ds_min_f64 and, since round 5, ds_min_u32 & co.: lds_min5_u32 in dpp_util.h) that are NOT
+    followed by `s_waitcnt ... lgkmcnt(0)` before control can reach a barrier or leave the straight line: between the atomic and its
+    wait only further LDS atomics may stand."""
     bad = []
     for i, ins in enumerate(insts):
-        if not ins.startswith("ds_min_f64"):
+        if not _is_lds_atomic(ins):
             continue
         ok = False
-        for nxt in insts[i + 1:i + 8]:
+        for nxt in insts[i + 1:i + 12]:
             op = nxt.split()[0]
             if op == "s_waitcnt" and "lgkmcnt(0)" in nxt:
                 ok = True
@@ -49,7 +62,7 @@ def unguarded_lds_atomics(insts):
             if op == "s_waitcnt" and nxt.split()[1:] in (["0"], ["0x0"]):
                 ok = True
                 break
-            if not op.startswith("ds_min_f64"):
+            if not _is_lds_atomic(nxt):
                 break  # anything else (a branch, a barrier, arithmetic) before the wait: the pairing is not guaranteed
         if not ok:
             bad.append(i)
@@ -57,17 +70,19 @@ def unguarded_lds_atomics(insts):
 
 
 def test_every_lds_min_atomic_is_waited_for_before_the_barrier(objects):
-    seen = 0
+    seen = {"ds_min_f64": 0, "ds_min_u32": 0}
     for obj in ("viterbi_words", "viterbi_fast"):
         _, dis = objects[obj]
         for kernel, insts in dis.items():
-            n = sum(1 for x in insts if x.startswith("ds_min_f64"))
-            if not n:
+            hits = [x.split()[0] for x in insts if _is_lds_atomic(x)]
+            if not hits:
                 continue
-            seen += n
+            for h in hits:
+                seen[h] = seen.get(h, 0) + 1
             # (a one-wave workgroup, decode_fast_kernel<64, ...>, has no s_barrier at all: the wait is still required there)
-            assert unguarded_lds_atomics(insts) == [], f"{kernel}: ds_min_f64 without s_waitcnt lgkmcnt(0) behind it"
-    assert seen >= 2 * 18, "the search kernels publish their minima through ds_min_f64; did the kernels change?"
+            assert unguarded_lds_atomics(insts) == [], f"{kernel}: LDS atomic without s_waitcnt lgkmcnt(0) behind it"
+    assert seen["ds_min_f64"] >= 2 * 18, "the search kernels publish their minima through ds_min_f64; did the kernels change?"
+    assert seen["ds_min_u32"] >= 5 * 18, "lds_min5_u32 (traceback[t], e_first) should show as ds_min_u32 in the search kernels"
 
 
 def test_the_checker_flags_a_kernel_without_the_wait(tmp_path):

@@ -91,9 +91,19 @@ def run_case(case, seed0=0, ragged=False, tmp=None):
         if nW <= 400 or n_utts <= 9:  # (big lexica -- two and three words per lane in the register layout -- on the small batches only: the oracle's cost)
             lm = (-np.log(rng.dirichlet(np.ones(nW), size=nW))).T.astype(np.float32).copy()
             tdp = np.array([[3.0, 0.0, 30.0, float(rng.choice([0.0, 5.0]))], [1.0, 0.0, 40.0, 2.0]], np.float32)
+            bg_off, bg_aut = word_off, automaton
+            if rng.random() < 0.3:
+                # round 5: a silence word of two to four states with forward / skip penalties of its own -- the dense
+                # state layout, where tdp[isSilence][1..2] apply inside silence and its copies (LinearSearch.cc:296-326)
+                tdp[1] = [float(rng.choice([0.0, 1.0])), float(rng.choice([0.0, 7.0])), float(rng.choice([3.0, 40.0])), 2.0]
+                si, extra = lex.silence_idx, rng.integers(0, lex.n_states, size=int(rng.integers(1, 4))).astype(np.uint16)
+                cut = int(word_off[si + 1])
+                bg_aut = np.concatenate([automaton[:cut], extra, automaton[cut:]]).astype(np.uint16)
+                bg_off = word_off.copy()
+                bg_off[si + 1:] += len(extra)
             acp = float(rng.choice([30.0, 120.0, pyoracle.FLT_MAX]))
             lmp = float(rng.choice([5.0, 25.0, pyoracle.FLT_MAX]))
-            bg = m.bigram(word_off, automaton, lex.silence_idx, lm, tdp)
+            bg = m.bigram(bg_off, bg_aut, lex.silence_idx, lm, tdp)
             gw, gs, gt, goff = corpus.recognize_bigram(bg, acp, lmp)
             try:
                 dw, ds, dt, doff = corpus.recognize_bigram(bg, acp, lmp, dense_states=True)  # register layout (short words) vs dense LDS image
@@ -104,7 +114,7 @@ def run_case(case, seed0=0, ragged=False, tmp=None):
                 assert np.array_equal(gw, dw) and np.array_equal(gt, dt) and np.array_equal(goff, doff) and np.array_equal(gs.view(np.uint32), ds.view(np.uint32)), (tag, "bigram layouts")
             for u in range(n_utts):
                 x = feats[int(off[u]):int(off[u + 1])]
-                w, s_, t_ = pyoracle.bigram_decode(want[int(off[u]):int(off[u + 1])], word_off, automaton, lex.silence_idx, lm, tdp, acp, lmp)
+                w, s_, t_ = pyoracle.bigram_decode(want[int(off[u]):int(off[u + 1])], bg_off, bg_aut, lex.silence_idx, lm, tdp, acp, lmp)
                 a, b = int(goff[u]), int(goff[u + 1])
                 assert np.array_equal(gw[a:b], w) and np.array_equal(gt[a:b], t_), (tag, "bigram", u)
                 assert np.array_equal(gs[a:b].view(np.uint32), s_.view(np.uint32)), (tag, "bigram score", u)
