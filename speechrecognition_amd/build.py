@@ -93,8 +93,29 @@ def build(force=False, verbose=False):
             raise RuntimeError("link failed:\n" + r.stdout)
         with open(LIB + ".stamp", "w") as f:
             f.write(link_stamp)
+    build_tools(force)
     write_build_info()
     return LIB
+
+
+TOOLS = os.path.join(os.path.dirname(HERE), "tools")
+DEVICE_TOOLS = ["wave_handoff_stress"]  # stand-alone device programs the GPU tests run (tools/<name>.hip -> tools/<name>)
+
+
+def build_tools(force=False):
+    """tools/<name>.hip -> tools/<name> for the device programs a GPU test runs; same content stamps as the library's objects."""
+    out = []
+    for name in DEVICE_TOOLS:
+        src, exe = os.path.join(TOOLS, name + ".hip"), os.path.join(TOOLS, name)
+        stamp = _stamp_of([_read(src)])
+        if force or not os.path.exists(exe) or _stored(exe + ".stamp") != stamp:
+            r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-Wno-unused-result", src, "-o", exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}")
+            with open(exe + ".stamp", "w") as f:
+                f.write(stamp)
+        out.append(exe)
+    return out
 
 
 BUILD_INFO = os.path.join(HERE, "BUILD_INFO.json")

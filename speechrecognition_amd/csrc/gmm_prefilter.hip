@@ -415,6 +415,9 @@ int gmm_prefilter_frames_per_tile() { return kPWaves * SR_P16_NB * 16; }
 #ifndef SR_R_BATCH
 #define SR_R_BATCH 4
 #endif
+#ifndef SR_R_XCDMAP
+#define SR_R_XCDMAP 0         // 1: state groups 2k, 2k + 1 on one XCD (probe, profiles/r5_refine_order_and_xcdmap.txt)
+#endif
 static constexpr int kRThreads = SR_R_THREADS;   // 3 waves per SIMD; the register budget of 168 holds x in FP64 (78) + pipeline
 static constexpr int kRWaves = kRThreads / 64;
 static constexpr int kRBatch = SR_R_BATCH;       // dimensions per software-pipeline stage of the candidate evaluation
@@ -437,7 +440,15 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
   extern __shared__ __attribute__((aligned(1024))) unsigned char panel_raw[];  // [SPW][state_bytes], 1 KB granular
   const uint32_t D = DT ? (uint32_t)DT : a.dim, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
+#if SR_R_XCDMAP
+  // probe: the two workgroups that fill the two 64-byte halves of one 128-byte table line on ONE XCD (blocks b and
+  // b + 8 share an XCD under the dispatcher's round-robin placement: speed only).  Within every full run of 16 blocks.
+  const uint32_t bid = blockIdx.x;
+  const uint32_t sg = (bid | 15u) < gridDim.x ? ((bid & ~15u) | ((bid & 7u) << 1) | ((bid >> 3) & 1u)) : bid;
+  const uint32_t s0 = sg * SPW;
+#else
   const uint32_t s0 = blockIdx.x * SPW;
+#endif
   const uint32_t ns = (s0 + SPW <= a.n_pstates) ? SPW : a.n_pstates - s0;  // (pseudo-)states of this workgroup
   const uint32_t state_bytes = (2u * D + 2u) * NS * 8u;
   const uint32_t D2 = D - (D & 1u);
@@ -728,10 +739,6 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
     // after the last iteration they are emptied.  One batch = <= 64 pairs of ONE state j (wave-uniform level, j, n):
     // level 1 evaluates each pair's second candidate, level 2 everything after the second.
     const bool last = it + 1 == n_it;
-    // table stores issued after the last list store (wave-uniform): SPW/2 row pieces, unless the data-dependent paths ran
-    uint32_t tail_stores;
-    if constexpr (CH == 1) tail_stores = (!chunk_shift && ns == SPW && __any(valid)) ? (uint32_t)(SPW / 2) : 0u;
-    else tail_stores = !__any(valid) ? 0u : (ns == SPW && RS >= 2) ? (uint32_t)(RS / 2) : (ns + CH - 1u) / CH;  // pairs, else one store per whole state
     for (;;) {
       uint32_t level, j, n;
       {
@@ -754,23 +761,16 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
       const uint32_t slot0 = ((level - 1u) * 8u + j) * kRingEntries;
       if (l1) cnt1 -= (uint64_t)n << (8u * j); else cnt2 -= (uint64_t)n << (8u * j);
       const bool live = (uint32_t)lane < n;
-      // This wave's earlier list stores must have landed before they are read back.  Stores complete in issue order,
-      // and the youngest ones are always table stores nobody reads here (the main pass' row pieces, SPW/2 of them when
-      // the workgroup owns SPW whole states; a previous batch's single update): waiting for all but those skips their
-      // HBM round trip.
-      if constexpr (CH == 1) {
-        if (tail_stores == (uint32_t)(SPW / 2)) __builtin_amdgcn_s_waitcnt(0x0F70 | (SPW / 2));  // vmcnt(SPW/2)
-        else if (tail_stores == 1u) __builtin_amdgcn_s_waitcnt(0x0F71);                          // vmcnt(1)
-        else __builtin_amdgcn_s_waitcnt(0x0F70);                                                  // vmcnt(0)
-      } else {
-        switch (tail_stores) {  // (at most SPW / CH <= 4 stores: one per whole state of a short last workgroup)
-          case 1: __builtin_amdgcn_s_waitcnt(0x0F71); break;
-          case 2: __builtin_amdgcn_s_waitcnt(0x0F72); break;
-          case 3: __builtin_amdgcn_s_waitcnt(0x0F73); break;
-          case 4: __builtin_amdgcn_s_waitcnt(0x0F74); break;
-          default: __builtin_amdgcn_s_waitcnt(0x0F70); break;
-        }
-      }
+      // The entries were stored by OTHER LANES OF THIS WAVE (the main pass above, a level-1 batch): a hand-off at wavefront scope.
+      // Round 5: ordered by the language's own construct instead of a hand-counted `s_waitcnt vmcnt(N)` (rounds 3-4 waited for all
+      // but the N youngest stores, on the claims that those are table stores and that stores complete in issue order -- true, and
+      // invisible to the compiler: a recompile that split a store or sank a load would have broken it silently).  On
+      // gfx950 a wave's vector-memory operations reach a given address in issue order, so the compiler emits NO wait for a
+      // wavefront-scope release / acquire pair (tests/test_isa_cpu.py pins that lowering); should a target ever need one, the
+      // fences are where it goes.  The asm barrier keeps the (non-atomic) entry accesses on their sides of the pair.
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       asm volatile("" ::: "memory");
       const uint32_t at = slot0 + have - n + (live ? (uint32_t)lane : 0u);
       const RingEntry en = ring[at];
@@ -808,16 +808,15 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
           cnt2 += (uint64_t)__builtin_popcountll(b) << (8u * j);
         }
       }
-      // the table update comes last: it is the one store the next batch need not wait for
+      // the table update comes last
       asm volatile("" ::: "memory");
       const bool lower = live && cur < before;
       if constexpr (CH == 1) {
-        tail_stores = (!chunk_shift && __any(lower)) ? 1u : 0u;
         if (lower) *o = cur;
       } else {
-        tail_stores = __any(lower) ? 1u : 0u;
         // global_atomic_min_f64 without a return value: issued behind this wave's earlier stores to the same entry (one wave owns a
-        // frame's row pieces and lists; vector memory operations of a wave reach an address in issue order)
+        // frame's row pieces and lists), from another lane: the same wavefront-scope ordering as the list hand-off above
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         if (lower) (void)__builtin_amdgcn_global_atomic_fmin_f64((__attribute__((address_space(1))) double*)o, cur);
       }
     }

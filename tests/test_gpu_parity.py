@@ -672,3 +672,16 @@ def test_fp16_accumulation_stays_inside_the_bounds_model():
     assert capi.lib().sr_probe_fp16_accumulation(0, C.byref(ok), C.byref(worst)) == 0
     print(f"worst |error| / (2^-24 sum|ab|) = {worst.value:.3f} (model: 87)")
     assert ok.value == 1 and worst.value <= 87.0
+
+
+def test_wave_handoff_stress():
+    """The memory ordering the refinement kernel's candidate lists rest on (csrc/gmm_prefilter.hip: entries stored by one lane and
+    loaded by another lane of the same wave with no wait in between; a no-return atomic minimum behind another lane's store to the
+    same address), hammered on this device: tools/wave_handoff_stress.hip, 1e9 hand-offs under load, none stale."""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "wave_handoff_stress")
+    assert os.path.exists(exe), "tools/wave_handoff_stress is built by __graft_entry__.build()"
+    r = subprocess.run([exe, "2000"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "0 stale entries, 0 wrong minima" in r.stdout, (r.stdout, r.stderr)

@@ -5,7 +5,13 @@
         atomics are inline asm, so the compiler's own wait before a barrier does not cover them: round 3 shipped a frame loop
         without the wait for a while and one traceback entry in ~1e5 came out wrong, run to run (DESIGN 4.4);
   (ii)  the headline kernels have no scratch (private segment): a spill there is a slow-down nobody would notice in a test;
-  (iii) the VGPR counts stay inside the occupancy each kernel's geometry assumes.
+  (iii) the VGPR counts stay inside the occupancy each kernel's geometry assumes;
+  (iv)  (round 5) the refinement kernel's list hand-off between the lanes of one wave -- entry stores, read back by other lanes;
+        a no-return atomic minimum behind other lanes' stores to the same address -- is ordered by wavefront-scope fences, not by
+        a hand-counted `s_waitcnt vmcnt(N)` as in rounds 3-4.  What the fences lower to on gfx950 (nothing: a wave's vector-memory
+        operations reach an address in issue order) is pinned here on a throw-away kernel, with the agent-scope form as the
+        control that the check can see a wait / write-back when one is needed; tools/wave_handoff_stress.hip hammers the pattern
+        on the device (tests/test_gpu_parity.py::test_wave_handoff_stress).
 The checker itself is tested on a throw-away kernel compiled here with the wait left out (it must be flagged)."""
 import os
 import subprocess
@@ -146,3 +152,68 @@ def test_vgpr_counts_fit_the_occupancy_the_kernels_are_launched_for(objects):
     for kernel, budget in VGPR_BUDGET.items():
         k = _find(objects, kernel)
         assert k["vgpr_count"] + k.get("agpr_count", 0) <= budget, (kernel, k["vgpr_count"], budget)
+
+
+HANDOFF_SRC = r'''
+#include <hip/hip_runtime.h>
+struct __attribute__((aligned(16))) E { unsigned a, b; double s; };
+__global__ void handoff(E* ring, double* table, const unsigned* perm, double* out) {
+  const unsigned lane = threadIdx.x, slot = perm[lane];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the permutation has arrived: nothing outstanding from here on)
+  ring[slot] = E{lane, lane * 3u, (double)lane};
+  table[lane] = 1.0;  // a younger store nobody reads back
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, SCOPE);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, SCOPE);
+  asm volatile("" ::: "memory");
+  const E e = ring[lane];  // stored by another lane of this wave
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, SCOPE);
+  (void)__builtin_amdgcn_global_atomic_fmin_f64((__attribute__((address_space(1))) double*)(table + (lane ^ 1u)), e.s);
+  out[lane] = e.s + e.a;
+}
+'''
+
+
+def _between_store_and_readback(insts):
+    """The instructions from the entry store (the 16-byte one) up to the first load behind it."""
+    i = next(k for k, x in enumerate(insts) if x.startswith("global_store_dwordx4"))
+    j = next(k for k in range(i + 1, len(insts)) if insts[k].startswith("global_load"))
+    return insts[i + 1:j]
+
+
+def test_wavefront_scope_handoff_needs_no_wait_on_gfx950(tmp_path):
+    src = tmp_path / "handoff.hip"
+    src.write_text(HANDOFF_SRC)
+    seen = {}
+    for scope in ("wavefront", "workgroup", "agent"):
+        co = tmp_path / f"{scope}.co"
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "--cuda-device-only", "--no-gpu-bundle-output", f'-DSCOPE="{scope}"', "-c", str(src),
+                        "-o", str(co)], check=True)
+        insts = next(v for k, v in isa_info.disassembly(str(co)).items() if "handoff" in k)
+        gap = _between_store_and_readback(insts)
+        seen[scope] = [x for x in gap if x.startswith(("s_waitcnt", "buffer_wbl2", "buffer_inv"))]
+        # the atomic minimum follows the read-back's use; between the fence in front of it and the atomic no write-back either
+        k = next(i for i, x in enumerate(insts) if x.startswith("global_atomic_min_f64"))
+        if scope != "agent":
+            assert not any(x.startswith(("buffer_wbl2", "buffer_inv")) for x in insts[:k]), (scope, insts[:k])
+    # one wave (and one CU: workgroup scope) needs nothing between the store and the other lane's load ...
+    assert seen["wavefront"] == [] and seen["workgroup"] == [], seen
+    # ... and the check would see it if it did: across CUs the compiler writes back, waits and invalidates
+    assert any(x.startswith("buffer_wbl2") for x in seen["agent"]) and any("vmcnt(0)" in x for x in seen["agent"]), seen
+
+
+def test_refinement_source_orders_its_lists_by_fences_not_by_counted_waits():
+    """gmm_refine_kernel: ONE explicit wait (vmcnt(0) behind the LDS fill), the list read-back and the atomic minimum behind
+    wavefront-scope fences.  A hand-counted vmcnt(N) in the batch loop (rounds 3-4) fails here."""
+    import re
+    text = open(os.path.join(ROOT, "speechrecognition_amd", "csrc", "gmm_prefilter.hip")).read()
+    body = text[text.index("void gmm_refine_kernel("):text.index("__global__ void transpose_feats_kernel")]
+    code = "\n".join(line.split("//")[0] for line in body.splitlines())
+    waits = re.findall(r"__builtin_amdgcn_s_waitcnt\(([^)]*)\)", code)
+    assert waits == ["0x0F70"], waits
+    assert "s_waitcnt" not in re.sub(r"__builtin_amdgcn_s_waitcnt\(0x0F70\)", "", code), "a wait in inline asm?"
+    at = code.index("const RingEntry en = ring[at];")
+    before = code[:at]
+    assert before.rindex('__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront")') > before.rindex("RingEntry{lf,"), "read-back must sit behind the fence pair"
+    tail = code[code.index("global_atomic_fmin_f64") - 400:code.index("global_atomic_fmin_f64")]
+    assert '__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront")' in tail
