@@ -57,7 +57,7 @@ SR_API int sr_abi_version(void);
 #define SR_GMM_EXACT 1  /* direct form replaying density_score_sse's operation order (Mixtures.cpp:645-690): bit-exact */
 #define SR_GMM_PREFILTER 2  /* bit-exact like SR_GMM_EXACT: a 16-bit MFMA prefilter selects the densities that can be the
                                minimum, FP64 replays only those.  Max-approx models with <= 128 densities per mixture and
-                               dim <= 46; any other model is scored by SR_GMM_EXACT's kernel instead (same bits). */
+                               dim <= 62; any other model is scored by SR_GMM_EXACT's kernel instead (same bits). */
 
 #define SR_GMM_DEFAULT 3  /* what a drop-in caller wants: the fastest kernel that reproduces MixtureModel::score for THIS model --
                              SR_GMM_PREFILTER (bit-exact) for max-approx models; for sum scoring (max-approx false,
@@ -276,9 +276,11 @@ SR_API int sr_recognize_bigram_corpus(sr_model* m, sr_corpus* c, sr_bigram* b, c
 /* Diagnostic: does the fp16 matrix pipe keep subnormal inputs on this device (an assumption of SR_GMM_PREFILTER's
  * error bound; when it does not hold, models are scored by SR_GMM_EXACT's kernel instead)? */
 SR_API int sr_probe_fp16_denormals(int device, int* preserved);
-/* ... and does its fp32 accumulation stay inside the bound's model?  Adversarial 96-term fp16 dot products with known exact
- * sums through the prefilter's own MFMA chain: within_model = 1 iff every |error| <= 87 * 2^-24 * sum |a_k b_k|;
- * worst_ratio (may be NULL) = the largest |error| / (2^-24 * sum |a_k b_k|) seen.  Both probes run at model creation. */
+/* ... and does its fp32 accumulation stay inside the bound's model?  Adversarial 96-term (dimension <= 46) and 128-term
+ * (dimension 47..62) fp16 dot products with known exact sums through the prefilter's own MFMA chains: within_model = 1 iff every
+ * |error| <= 87 (96 terms) / 132 (128 terms) * 2^-24 * sum |a_k b_k|; worst_ratio (may be NULL) = the largest
+ * |error| / (2^-24 * sum |a_k b_k|) seen, the 128-term ratios scaled by 87 / 132.  The probes run at model creation (the chain
+ * length the model uses). */
 SR_API int sr_probe_fp16_accumulation(int device, int* within_model, double* worst_ratio);
 
 /* ---- measurement --------------------------------------------------------------------------------

@@ -34,8 +34,12 @@
 // (Mixtures.cpp:645-690): the minimum over the candidates is the minimum over all densities, bit for bit what
 // MixtureModel::score returns.
 //
+// K = 128 (round 5, dim 47..62: four k-steps): <= 127 + 4 additions -> the same formula with 132 in place of 87:
+//    kKappa16 needs 9.85e-4 (1.05e-3 stays), kKonst16 = 1.6e-5 (2 x 132 * 2^-24 = 1.57e-5), kAbs16 = 7.0e-7 (2 x 2^-25 (1 + 2^-11) sqrt(128)
+//    = 6.75e-7); the accumulation probe runs its 128-term chain against 132 * 2^-24 on such a model's device.
+//
 // Limits of this path: max-approx only, <= 128 densities per mixture (a mixture of more than 32 spans 2 or 4
-// consecutive 32-slot pseudo-states), dim <= 46 (K = 2*dim + 3 <= 96); any other model is scored by the exact FP64
+// consecutive 32-slot pseudo-states), dim <= 62 (K = 2*dim + 3 <= 128); any other model is scored by the exact FP64
 // kernel (same bits).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -65,7 +69,9 @@ static constexpr int kGroupBlocks = 8;     // every 4-state group is padded to 8
 // stage first, so that the pipeline runs across stage boundaries and the LDS-DMA of stage s+2 goes into the buffer
 // everybody has just finished reading.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-static constexpr float kKappa16 = 1.05e-3f, kKonst16 = 1.1e-5f, kAbs16 = 6.0e-7f;
+static constexpr float kKappa16 = 1.05e-3f;
+template <int KS32> struct PfBound { static constexpr float kKonst16 = 1.1e-5f, kAbs16 = 6.0e-7f; };  // K <= 96 (file header)
+template <> struct PfBound<4> { static constexpr float kKonst16 = 1.6e-5f, kAbs16 = 7.0e-7f; };        // K = 128
 
 __device__ inline uint32_t pack_f16x2(float lo, float hi) {
   const _Float16 l = (_Float16)lo, h = (_Float16)hi;
@@ -202,6 +208,7 @@ __global__ __launch_bounds__(kPWaves * 64, (NB <= 2 ? 3 : 2)) void gmm_prefilter
     // ---- candidate mask of state slot g of this group, for the lane's frame(s) (scaled units) ---------------------
     const float2 nk = reinterpret_cast<const float2*>(a.grp_anorm)[4u * grp + g];  // sA |a|, sA |konst| (rounded up)
     // 2 eps = lim1 |b| + lim0 (the bound of the file header, the frame's part factored out: 2 instructions per frame block)
+    constexpr float kKonst16 = PfBound<KS32>::kKonst16, kAbs16 = PfBound<KS32>::kAbs16;
     const float lim1 = 2.0f * (kKappa16 * nk.x + kAbs16), lim0 = 2.0f * (kKonst16 * nk.y + kAbs16 * nk.x);
 #pragma unroll
     for (int nb = 0; nb < NB; nb++) {
@@ -268,18 +275,20 @@ hipError_t probe_fp16_denormals(hipStream_t stream, bool* preserved) {
 }
 
 // ---- accumulation probe ------------------------------------------------------------------------------------------
-// One 16x16 tile through the kernel's own MFMA chain (three k-steps of 32, accumulator from zero): A[16][96] and B[96][16]
+// One 16x16 tile through the kernel's own MFMA chain (KS k-steps of 32, accumulator from zero): A[16][K] and B[K][16], K = 32 KS,
 // fp16 from global memory, D[16][16] fp32 back.  The host builds the operands (below) and knows every exact sum.
+template <int KS>
 __global__ void fp16_accumulation_probe_kernel(const _Float16* A, const _Float16* B, float* out) {
+  constexpr int K = 32 * KS;
   const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
   v4f acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int ks = 0; ks < 3; ks++) {
+  for (int ks = 0; ks < KS; ks++) {
     f16x8 a, b;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       const int k = 32 * ks + 8 * q + j;
-      a[j] = A[r * 96 + k];   // A operand: row = lane & 15, k = 32 ks + 8 (lane >> 4) + j
+      a[j] = A[r * K + k];    // A operand: row = lane & 15, k = 32 ks + 8 (lane >> 4) + j
       b[j] = B[k * 16 + r];   // B operand: column = lane & 15, same k
     }
     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
@@ -289,34 +298,37 @@ __global__ void fp16_accumulation_probe_kernel(const _Float16* A, const _Float16
 }
 
 // Adversarial operand sets, all products exact in fp32 (11 x 11 significant bits) and all exact sums exact in double:
-//   family 0  one product of 2^23 and 95 products of 0.75: every addition to the big term is a tie-or-worse rounding
-//             (a truncating accumulator ends about 50 units low, the model allows 43)
-//   family 1  cancellation: 47 pairs +-(2^10 + d_k) with different small d_k, residue ~ 2^-4 .. 2^2 against sum |p| ~ 1e5
-//   family 2  96 equal products (1 + 2^-10)^2: a short internal accumulator or a wrong k order shows at once
+//   family 0  one product of 2^23 and K - 1 products of 0.75: every addition to the big term is a tie-or-worse rounding
+//             (at K = 96 a truncating accumulator ends about 50 units low, the model allows 43)
+//   family 1  cancellation: K / 2 - 1 pairs +-(2^10 + d_k) with different small d_k, residue ~ 2^-4 .. 2^2 against sum |p| ~ 1e5
+//   family 2  K equal products (1 + 2^-10)^2: a short internal accumulator or a wrong k order shows at once
 //   family 3  random signs and magnitudes over 12 binades
-// worst_ratio (optional) receives max |error| / (2^-24 sum |p|) -- the model allows 87.
-hipError_t probe_fp16_accumulation(hipStream_t stream, bool* ok, double* worst_ratio) {
+// ks32 = 3 (K = 96) or 4 (K = 128).  worst_ratio (optional) receives max |error| / (2^-24 sum |p|) -- the model allows 87 / 132.
+hipError_t probe_fp16_accumulation(hipStream_t stream, int ks32, bool* ok, double* worst_ratio) {
+  if (ks32 != 3 && ks32 != 4) return hipErrorInvalidValue;
   const int kCases = 8;  // 8 tiles of 16 x 16 dot products
-  std::vector<_Float16> hA((size_t)kCases * 16 * 96), hB((size_t)kCases * 96 * 16);
+  const int K = 32 * ks32;
+  const double allowed = ks32 == 3 ? 87.0 : 132.0;
+  std::vector<_Float16> hA((size_t)kCases * 16 * K), hB((size_t)kCases * K * 16);
   uint64_t rng = 0x9E3779B97F4A7C15ull;
   auto next = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
   for (int t = 0; t < kCases; t++) {
-    _Float16* A = hA.data() + (size_t)t * 16 * 96;
-    _Float16* B = hB.data() + (size_t)t * 96 * 16;
-    for (int k = 0; k < 96; k++)
+    _Float16* A = hA.data() + (size_t)t * 16 * K;
+    _Float16* B = hB.data() + (size_t)t * K * 16;
+    for (int k = 0; k < K; k++)
       for (int c = 0; c < 16; c++) B[k * 16 + c] = (_Float16)1.0f;
     for (int r = 0; r < 16; r++)
-      for (int k = 0; k < 96; k++) {
+      for (int k = 0; k < K; k++) {
         float a = 0.f;
         const int fam = (t * 16 + r) & 3;
-        if (fam == 0) a = k == (r * 5) % 96 ? 4096.0f : 0.75f;                     // times b = 2048 / 1 below
-        else if (fam == 1) a = k >= 94 ? 0.f : ((k & 1) ? -1.f : 1.f) * (1024.0f + (float)(((k >> 1) * 7 + r) % 64) * ((k & 1) ? 0.5f : 0.53125f));
+        if (fam == 0) a = k == (r * 5) % K ? 4096.0f : 0.75f;                      // times b = 2048 / 1 below
+        else if (fam == 1) a = k >= K - 2 ? 0.f : ((k & 1) ? -1.f : 1.f) * (1024.0f + (float)(((k >> 1) * 7 + r) % 64) * ((k & 1) ? 0.5f : 0.53125f));
         else if (fam == 2) a = 1.0009765625f;
         else { const uint64_t u = next(); a = ((u & 1) ? -1.f : 1.f) * (1.0f + (float)((u >> 8) & 1023) / 1024.0f) * (float)(1u << ((u >> 20) % 12)); }
-        A[r * 96 + k] = (_Float16)a;
+        A[r * K + k] = (_Float16)a;
       }
     // column-side factors: column c scales family 0's big term to 2^23 and gives the others a second 11-bit factor
-    for (int k = 0; k < 96; k++)
+    for (int k = 0; k < K; k++)
       for (int c = 0; c < 16; c++) {
         const uint64_t u = next();
         float b = 1.0f + (float)((u >> 5) % 1024) / 1024.0f;                          // [1, 2): full 11-bit significand
@@ -326,7 +338,7 @@ hipError_t probe_fp16_accumulation(hipStream_t stream, bool* ok, double* worst_r
       }
     for (int c = 0; c < 16; c++)  // family 0 rows meet their 2048 on one k only (any column): overwrite that k's factor
       for (int r = 0; r < 16; r++)
-        if (((t * 16 + r) & 3) == 0) B[((r * 5) % 96) * 16 + c] = (_Float16)2048.0f;
+        if (((t * 16 + r) & 3) == 0) B[((r * 5) % K) * 16 + c] = (_Float16)2048.0f;
   }
   _Float16 *dA = nullptr, *dB = nullptr;
   float* dO = nullptr;
@@ -338,7 +350,8 @@ hipError_t probe_fp16_accumulation(hipStream_t stream, bool* ok, double* worst_r
   e = hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(dB, hB.data(), hB.size() * 2, hipMemcpyHostToDevice);
   for (int t = 0; t < kCases && e == hipSuccess; t++) {
-    hipLaunchKernelGGL(fp16_accumulation_probe_kernel, dim3(1), dim3(64), 0, stream, dA + (size_t)t * 16 * 96, dB + (size_t)t * 96 * 16, dO + (size_t)t * 256);
+    if (ks32 == 3) hipLaunchKernelGGL(fp16_accumulation_probe_kernel<3>, dim3(1), dim3(64), 0, stream, dA + (size_t)t * 16 * K, dB + (size_t)t * K * 16, dO + (size_t)t * 256);
+    else hipLaunchKernelGGL(fp16_accumulation_probe_kernel<4>, dim3(1), dim3(64), 0, stream, dA + (size_t)t * 16 * K, dB + (size_t)t * K * 16, dO + (size_t)t * 256);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -351,14 +364,14 @@ hipError_t probe_fp16_accumulation(hipStream_t stream, bool* ok, double* worst_r
     for (int r = 0; r < 16; r++)
       for (int c = 0; c < 16; c++) {
         double exact = 0.0, mag = 0.0;
-        for (int k = 0; k < 96; k++) {
-          const double p = (double)(float)hA[((size_t)t * 16 + r) * 96 + k] * (double)(float)hB[((size_t)t * 96 + k) * 16 + c];
+        for (int k = 0; k < K; k++) {
+          const double p = (double)(float)hA[((size_t)t * 16 + r) * K + k] * (double)(float)hB[((size_t)t * K + k) * 16 + c];
           exact += p;  // exact: every product has <= 22 significant bits within 2^-10 .. 2^24
           mag += p < 0 ? -p : p;
         }
         const double err = std::fabs((double)got[(size_t)t * 256 + r * 16 + c] - exact);
         const double ratio = err / (mag * 5.9604644775390625e-8);
-        if (!(ratio <= 87.0)) fine = false;  // (NaN fails)
+        if (!(ratio <= allowed)) fine = false;  // (NaN fails)
         if (ratio > worst || ratio != ratio) worst = ratio;
       }
   *ok = fine;
@@ -373,6 +386,7 @@ hipError_t launch_gmm_prefilter(const GmmPrefilterArgs& a, int ks32, hipStream_t
     case 1: hipLaunchKernelGGL((gmm_prefilter16_kernel<1, SR_P16_NB>), grid, block, 0, stream, a); break;
     case 2: hipLaunchKernelGGL((gmm_prefilter16_kernel<2, SR_P16_NB>), grid, block, 0, stream, a); break;
     case 3: hipLaunchKernelGGL((gmm_prefilter16_kernel<3, SR_P16_NB>), grid, block, 0, stream, a); break;
+    case 4: hipLaunchKernelGGL((gmm_prefilter16_kernel<4, SR_P16_NB>), grid, block, 0, stream, a); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -419,8 +433,14 @@ int gmm_prefilter_frames_per_tile() { return kPWaves * SR_P16_NB * 16; }
 #define SR_R_XCDMAP 0         // 1: state groups 2k, 2k + 1 on one XCD (probe, profiles/r5_refine_order_and_xcdmap.txt)
 #endif
 static constexpr int kRThreads = SR_R_THREADS;   // 3 waves per SIMD; the register budget of 168 holds x in FP64 (78) + pipeline
-static constexpr int kRWaves = kRThreads / 64;
+static constexpr int kRThreadsWide = 512;        // padded dimension 55 / 63: 2 waves per SIMD, a budget of 256 registers (x in FP64: up to 126)
+static constexpr int kRWaves = kRThreads / 64;   // (the ring workspace is sized for the larger workgroup)
 static constexpr int kRBatch = SR_R_BATCH;       // dimensions per software-pipeline stage of the candidate evaluation
+#ifndef SR_R_BATCH_WIDE
+#define SR_R_BATCH_WIDE 8
+#endif
+static constexpr int kRBatchWide = SR_R_BATCH_WIDE;  // the same at 512 threads (2 waves per SIMD: fewer waves to hide an LDS read behind; 8 against 4:
+                                                     // 2-3 % at dim 50 / 62, profiles/r5_cliffs.txt)
 static constexpr uint32_t kRingEntries = 128;    // per (wave, level, state): < 64 pending + <= 64 appended per iteration
 static constexpr uint32_t kRingLists = 2 * 8 * kRingEntries;  // entries per wave: [level][state][128]
 static constexpr uint32_t kRingWave = 4 * kRingLists;         // u32 per wave: 16-byte entries
@@ -433,12 +453,23 @@ struct __attribute__((packed, aligned(4))) RowPiece { float v[4]; };  // 16 byte
 // the main pass evaluates ONE candidate per state -- the first of the state's first non-empty mask (round 4; until then it
 // evaluated one per pseudo-state and dropped the results of the empty ones: half of the FP64 work at 64 densities) -- and
 // everything else goes to the lists of the pseudo-state it belongs to.
-template <int DT, int NS, int SPW, int CH>  // DT = compile-time feature dimension (0: run-time a.dim, features re-read from featsT)
-__global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) {
+// DT = the PADDED feature dimension, always odd (round 5; gmm_refine_padded_dim): density_score_sse sums dimensions 0 .. D - D % 2 - 1
+// in pairs and adds an odd D's last dimension to l0 + l1 afterwards (Mixtures.cpp:651-675).  A model of any dimension D <= DT runs the
+// DT instantiation on planes and features laid out as
+//     pair dimensions 0 .. D - D % 2 - 1 | zeros up to DT - 2 | tail: dimension D - 1 if D is odd, else zeros
+// because a padded dimension computes (0 - 0)^2 * 0 = +0.0 and l + 0.0 == l bit for bit (l is never -0; NaN and inf stay what they
+// are), and an even D's empty tail adds +0.0 to dist = l0 + l1.  Rounds 2-4 had a run-time-dimension instantiation (DT = 0) for every
+// dimension but 25 and 39 that re-read each feature from memory per evaluation; it is gone.
+// NT = threads per workgroup: 768 while the features fit a 168-register budget (DT <= 47: 161 registers there), 512 beyond (2 waves per
+// SIMD hide the LDS reads worse: dim 40 in the 47 instantiation took 27.6 ms at 512 threads, 21.2 at 768; profiles/r5_cliffs.txt).
+template <int DT, int NS, int SPW, int CH, int NT = kRThreads>
+__global__ __launch_bounds__(NT) void gmm_refine_kernel(GmmRefineArgs a) {
+  static_assert(DT > 0 && (DT & 1), "padded dimension: odd");
+  constexpr int kRThreads = NT, kRWaves = NT / 64;  // (shadow the file-scope defaults)
   static_assert(CH == 1 || CH == 2 || CH == 4, "chunks per state");
   static_assert(SPW % CH == 0 && (CH == 1 || SPW % 4 == 0), "a state's chunks live in one workgroup");
   extern __shared__ __attribute__((aligned(1024))) unsigned char panel_raw[];  // [SPW][state_bytes], 1 KB granular
-  const uint32_t D = DT ? (uint32_t)DT : a.dim, tid = threadIdx.x;
+  const uint32_t D = (uint32_t)DT, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
 #if SR_R_XCDMAP
   // probe: the two workgroups that fill the two 64-byte halves of one 128-byte table line on ONE XCD (blocks b and
@@ -451,7 +482,6 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
 #endif
   const uint32_t ns = (s0 + SPW <= a.n_pstates) ? SPW : a.n_pstates - s0;  // (pseudo-)states of this workgroup
   const uint32_t state_bytes = (2u * D + 2u) * NS * 8u;
-  const uint32_t D2 = D - (D & 1u);
   const uint64_t f_begin = (uint64_t)blockIdx.y * a.frames_per_split;
   const uint64_t f_end = (f_begin + a.frames_per_split < a.n_frames) ? f_begin + a.frames_per_split : a.n_frames;
 
@@ -472,9 +502,7 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
   if (f_begin >= f_end) return;  // (after the barrier: whole workgroup)
 
   uint32_t n_eval = 0;  // evaluations of this WAVE (profiling; a scalar: counted by ballots, no per-lane arithmetic)
-  double x[DT ? DT : 1];
-  uint64_t fx = 0;  // frame whose features x[] / X() hold
-  bool fx_T = true; // (run-time dimension only) X() reads it from featsT / from the row-major buffer
+  double x[DT];
   // featsT through a buffer descriptor: address = base + 4 * f (VGPR) + 4 * k * ld (SGPR, stepped by scalar adds) -- one
   // VGPR offset for all dimensions instead of 39 loop-invariant 64-bit row pointers that spill out of the SGPR file and
   // come back through v_readlane.  (dim * ld * 4 < 2^32: the launcher checks.)
@@ -482,32 +510,24 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
       const_cast<float*>(a.featsT), 0, (int)0xFFFFFFFFu, 0x00020000);
   const uint32_t ld4 = (uint32_t)a.n_frames_ld * 4u;
   auto load_x = [&](uint64_t f) __attribute__((always_inline)) {
-    fx = f; fx_T = true;
-    if (DT) {
-      const uint32_t voff = (uint32_t)f * 4u;
+    const uint32_t voff = (uint32_t)f * 4u;
 #pragma unroll
-      for (int k = 0; k < DT; k++)
-        x[DT ? k : 0] = (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(featsT_rsrc, voff, (uint32_t)k * ld4, 0));
-    }
+    for (int k = 0; k < DT; k++)
+      x[k] = (double)__builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(featsT_rsrc, voff, (uint32_t)k * ld4, 0));
   };
-  // the same from the row-major buffer: for the batches below, whose 64 lanes hold 64 unrelated frames -- a frame's
-  // features are 2 cache lines there against one line per dimension in featsT (measured: 11 ms of L2 traffic)
+  // the same from the row-major buffer (rows of DT floats: the corpus' own when its dimension is DT, else the padded copy the
+  // transpose kernel writes): for the batches below, whose 64 lanes hold 64 unrelated frames -- a frame's features are 2 cache
+  // lines there against one line per dimension in featsT (measured: 11 ms of L2 traffic)
   auto load_x_row = [&](uint64_t f) __attribute__((always_inline)) {
-    fx = f; fx_T = false;
-    if (DT) {
-      const float* xr = a.feats + f * (uint64_t)DT;
+    const float* xr = a.feats + f * (uint64_t)DT;
 #pragma unroll
-      for (int q = 0; q < DT / 4; q++) {
-        const RowPiece t = reinterpret_cast<const RowPiece*>(xr)[q];
+    for (int q = 0; q < DT / 4; q++) {
+      const RowPiece t = reinterpret_cast<const RowPiece*>(xr)[q];
 #pragma unroll
-        for (int i = 0; i < 4; i++) x[DT ? 4 * q + i : 0] = (double)t.v[i];
-      }
-#pragma unroll
-      for (int k = DT - DT % 4; k < DT; k++) x[DT ? k : 0] = (double)xr[k];
+      for (int i = 0; i < 4; i++) x[4 * q + i] = (double)t.v[i];
     }
-  };
-  auto X = [&](uint32_t k) -> double {
-    return DT ? x[DT ? k : 0] : (double)(fx_T ? a.featsT[(uint64_t)k * a.n_frames_ld + fx] : a.feats[fx * D + k]);
+#pragma unroll
+    for (int k = DT - DT % 4; k < DT; k++) x[k] = (double)xr[k];
   };
   // score of the density whose plane column starts at LDS address `col0`, in density_score_sse's operation order
   auto evaluate = [&](const unsigned char* col0) __attribute__((always_inline)) -> double {
@@ -516,35 +536,36 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
     const volatile __attribute__((address_space(3))) double* col =
         (const volatile __attribute__((address_space(3))) double*)col0;  // col[plane * NS]
     double l0 = 0.0, l1 = 0.0, dist, score;
-    if (DT) {
-      // software pipeline over batches of kRBatch dimensions: the reads of batch b+1 are issued before the
+    {
+      constexpr int RB = NT == kRThreadsWide ? kRBatchWide : kRBatch;
+      // software pipeline over batches of RB dimensions: the reads of batch b+1 are issued before the
       // arithmetic of batch b (volatile reads are not moved by the compiler, hence the explicit fences)
-      constexpr int NB_ = (DT + 1 + kRBatch - 1) / kRBatch;  // plane pairs 0..DT-1 = dimensions, pair DT = (norm, logw)
-      double pm[2][kRBatch], pv[2][kRBatch];
+      constexpr int NB_ = (DT + 1 + RB - 1) / RB;  // plane pairs 0..DT-1 = dimensions, pair DT = (norm, logw)
+      double pm[2][RB], pv[2][RB];
 #pragma unroll
-      for (int i = 0; i < kRBatch; i++)
+      for (int i = 0; i < RB; i++)
         if (i <= DT) { pm[0][i] = col[(2 * i) * NS]; pv[0][i] = col[(2 * i + 1) * NS]; }
 #pragma unroll
       for (int b = 0; b < NB_; b++) {
         const int cur = b & 1;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < kRBatch; i++) {
-          const int k = (b + 1) * kRBatch + i;
+        for (int i = 0; i < RB; i++) {
+          const int k = (b + 1) * RB + i;
           if (k <= DT) { pm[cur ^ 1][i] = col[(2 * k) * NS]; pv[cur ^ 1][i] = col[(2 * k + 1) * NS]; }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < kRBatch; i++) {
-          const int k = b * kRBatch + i;
+        for (int i = 0; i < RB; i++) {
+          const int k = b * RB + i;
           if (k < (int)(DT - (DT & 1))) {
-            double u = x[DT ? k : 0] - pm[cur][i];
+            double u = x[k] - pm[cur][i];
             u = u * u;
             u = u * pv[cur][i];
             if (k & 1) l1 = l1 + u; else l0 = l0 + u;
           } else if (k == DT - 1) {  // odd dimension count: scalar tail (Mixtures.cpp:680-683)
             dist = l0 + l1;
-            const double t = x[DT ? k : 0] - pm[cur][i];
+            const double t = x[k] - pm[cur][i];
             dist += t * t * pv[cur][i];
           } else if (k == DT) {
             if (!(DT & 1)) dist = l0 + l1;
@@ -556,24 +577,6 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
         // the arithmetic sinks below all 80 reads and their 160 destination registers spill
         asm volatile("" : "+v"(l0), "+v"(l1));
       }
-    } else {
-      for (uint32_t k = 0; k < D2; k += 2) {
-        double u = X(k) - col[(2 * k) * NS];
-        u = u * u;
-        u = u * col[(2 * k + 1) * NS];
-        l0 = l0 + u;
-        double v = X(k + 1) - col[(2 * k + 2) * NS];
-        v = v * v;
-        v = v * col[(2 * k + 3) * NS];
-        l1 = l1 + v;
-      }
-      dist = l0 + l1;
-      if (D & 1u) {
-        const double t = X(D - 1) - col[(2 * (D - 1)) * NS];
-        dist += t * t * col[(2 * (D - 1) + 1) * NS];
-      }
-      score = col[(2 * D) * NS] + dist / 2;
-      score -= col[(2 * D + 1) * NS];
     }
     return score;
   };
@@ -826,44 +829,74 @@ __global__ __launch_bounds__(kRThreads) void gmm_refine_kernel(GmmRefineArgs a) 
   }
 }
 
-__global__ void transpose_feats_kernel(const float* feats, uint64_t n_frames, uint32_t dim, uint64_t ldT, float* out) {
+// featsT[k][f] for the refinement's main pass, in the PADDED dimension order of gmm_refine_kernel (dp rows: the pair dimensions, zero
+// rows, the odd tail last), and -- when dp differs from the corpus' dimension -- the same rows of dp floats row-major (featsP) for the
+// batches; with dp == dim the batches read the corpus' own rows and featsP is null.
+__device__ inline uint32_t padded_source_dim(uint32_t k, uint32_t dim, uint32_t dp) {  // which real dimension sits in padded slot k (dim: none)
+  const uint32_t pairs = dim - (dim & 1u);
+  return k < pairs ? k : (k == dp - 1u && (dim & 1u)) ? dim - 1u : dim;
+}
+__global__ void transpose_feats_kernel(const float* feats, uint64_t n_frames, uint32_t dim, uint32_t dp, uint64_t ldT, float* out, float* featsP) {
   __shared__ float tile[64][65];
   const uint64_t f0 = (uint64_t)blockIdx.x * 64;
-  for (uint32_t d0 = 0; d0 < dim; d0 += 64) {
+  for (uint32_t d0 = 0; d0 < dp; d0 += 64) {
     for (uint32_t i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
       const uint32_t fr = i / 64, d = i % 64;
-      tile[fr][d] = (f0 + fr < n_frames && d0 + d < dim) ? feats[(f0 + fr) * dim + d0 + d] : 0.0f;
+      const uint32_t src = d0 + d < dp ? padded_source_dim(d0 + d, dim, dp) : dim;
+      tile[fr][d] = (f0 + fr < n_frames && src < dim) ? feats[(f0 + fr) * dim + src] : 0.0f;
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
       const uint32_t d = i / 64, fr = i % 64;
-      if (f0 + fr < n_frames && d0 + d < dim) out[(uint64_t)(d0 + d) * ldT + f0 + fr] = tile[fr][d];
+      if (f0 + fr < n_frames && d0 + d < dp) out[(uint64_t)(d0 + d) * ldT + f0 + fr] = tile[fr][d];
+    }
+    if (featsP) {
+      for (uint32_t i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
+        const uint32_t fr = i / 64, d = i % 64;
+        if (f0 + fr < n_frames && d0 + d < dp) featsP[(f0 + fr) * dp + d0 + d] = tile[fr][d];
+      }
     }
     __syncthreads();
   }
 }
 
-hipError_t launch_transpose_feats(const float* feats, uint64_t n_frames, uint32_t dim, uint64_t ldT, float* out, hipStream_t stream) {
+hipError_t launch_transpose_feats(const float* feats, uint64_t n_frames, uint32_t dim, uint32_t dp, uint64_t ldT, float* out, float* featsP,
+                                  hipStream_t stream) {
   if (n_frames == 0) return hipSuccess;
-  hipLaunchKernelGGL(transpose_feats_kernel, dim3((unsigned)((n_frames + 63) / 64)), dim3(256), 0, stream, feats, n_frames, dim, ldT, out);
+  if (dp < dim || (dp != dim && !featsP)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(transpose_feats_kernel, dim3((unsigned)((n_frames + 63) / 64)), dim3(256), 0, stream, feats, n_frames, dim, dp, ldT, out,
+                     dp != dim ? featsP : nullptr);
   return hipGetLastError();
 }
 
-int gmm_refine_slots(uint32_t max_dens) { return max_dens <= 8 ? 8 : max_dens <= 16 ? 16 : 32; }
+int gmm_refine_slots(uint32_t max_dens, uint32_t padded_dim) { return padded_dim > 39 ? 32 : max_dens <= 8 ? 8 : max_dens <= 16 ? 16 : 32; }
 
+// The padded (odd) dimension a model of dimension `dim` is refined in; 0: beyond the refinement's instantiations (dim > 62).
+// 25 and 39 are the reference's real-speech and the benchmark's dimensions and stay exact fits.
+uint32_t gmm_refine_padded_dim(uint32_t dim) {
+  static const uint32_t bounds[] = {9, 17, 25, 33, 39, 47, 55, 63};
+  // an odd dim needs its pairs (dim - 1) and the tail: bound >= dim; an even dim needs its pairs (dim) below the tail: bound >= dim + 1
+  const uint32_t need = dim | 1u;
+  for (uint32_t b : bounds)
+    if (need <= b) return b;
+  return 0;
+}
+
+static int refine_threads(uint32_t dp) { return dp <= 47 ? kRThreads : kRThreadsWide; }
+static int refine_spw(const GmmRefineArgs& a) {
+  // 8 states per workgroup when their parameters fit the 160 KiB of LDS (dim <= 39 at 32 slots), else 4
+  return (size_t)(2 * a.dim + 2) * a.n_slots * 8 * 8 <= 160 * 1024 ? 8 : 4;
+}
 static void refine_grid(const GmmRefineArgs& a, int spw, uint32_t* n_sgroups, uint64_t* splits, uint64_t* frames_per_split) {
+  const uint64_t nt = (uint64_t)refine_threads(a.dim);
   *n_sgroups = (a.n_pstates + spw - 1) / spw;
   // two rounds of workgroups over the 256 CUs at least (one workgroup per CU when it takes the whole LDS), without
   // cutting the frame range below one pass of the threads
   uint64_t sp = std::max<uint64_t>(1, (512 + *n_sgroups - 1) / *n_sgroups);
-  sp = std::min<uint64_t>(sp, (a.n_frames + kRThreads - 1) / kRThreads);
+  sp = std::min<uint64_t>(sp, (a.n_frames + nt - 1) / nt);
   sp = std::max<uint64_t>(sp, 1);
   *frames_per_split = (a.n_frames + sp - 1) / sp;
   *splits = *frames_per_split ? (a.n_frames + *frames_per_split - 1) / *frames_per_split : 1;
-}
-static int refine_spw(const GmmRefineArgs& a) {
-  // 8 states per workgroup when their parameters fit the 160 KiB of LDS (dim <= 39 at 32 slots), else 4
-  return (a.n_slots < 32 || (size_t)(2 * a.dim + 2) * a.n_slots * 8 * 8 <= 160 * 1024) ? 8 : 4;
 }
 size_t gmm_refine_ring_words(const GmmRefineArgs& a) {
   uint32_t g; uint64_t sp, fps;
@@ -871,41 +904,62 @@ size_t gmm_refine_ring_words(const GmmRefineArgs& a) {
   return (size_t)g * sp * kRWaves * kRingWave;
 }
 
-template <int NS, int SPW, int CH = 1>
-static hipError_t launch_refine_ns(const GmmRefineArgs& a0, hipStream_t stream) {
+template <int DT, int NS, int SPW, int CH, int NT>
+static hipError_t launch_refine_one(const GmmRefineArgs& a0, hipStream_t stream) {
   GmmRefineArgs a = a0;
-  const size_t state_bytes = (size_t)(2 * a.dim + 2) * NS * 8;
+  const size_t state_bytes = (size_t)(2 * DT + 2) * NS * 8;
   const size_t smem = (SPW * state_bytes + 1023) & ~(size_t)1023;
   uint32_t n_sgroups;
   uint64_t splits;
   refine_grid(a, SPW, &n_sgroups, &splits, &a.frames_per_split);
-  const dim3 grid(n_sgroups, (unsigned)splits), block(kRThreads);
-  auto go = [&](auto kernel) {
-    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kernel, grid, block, smem, stream, a);
-    return hipGetLastError();
-  };
-  switch (a.dim) {
-    case 39: return go(gmm_refine_kernel<39, NS, SPW, CH>);
-    case 25: return go(gmm_refine_kernel<25, NS, SPW, CH>);
-    default: return go(gmm_refine_kernel<0, NS, SPW, CH>);
-  }
+  const dim3 grid(n_sgroups, (unsigned)splits), block(NT);
+  auto kernel = gmm_refine_kernel<DT, NS, SPW, CH, NT>;
+  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kernel, grid, block, smem, stream, a);
+  return hipGetLastError();
 }
 
+// padded dimension <= 39: 768 threads, 8 states per workgroup, panels of 8 / 16 / 32 slots
+template <int DT>
+static hipError_t launch_refine_narrow(const GmmRefineArgs& a, hipStream_t stream) {
+  switch (a.n_slots) {
+    case 8: return launch_refine_one<DT, 8, 8, 1, kRThreads>(a, stream);
+    case 16: return launch_refine_one<DT, 16, 8, 1, kRThreads>(a, stream);
+    case 32:  // (a mixture of more than 32 densities always has 32-slot panels)
+      if (a.chunks == 2) return launch_refine_one<DT, 32, 8, 2, kRThreads>(a, stream);
+      if (a.chunks == 4) return launch_refine_one<DT, 32, 8, 4, kRThreads>(a, stream);
+      return launch_refine_one<DT, 32, 8, 1, kRThreads>(a, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+// padded dimension 55 / 63: 512 threads (2 waves per SIMD: the features alone take up to 126 registers), 4 states per workgroup
+// (8 would not fit the LDS at 32 slots), 32-slot panels whatever the model's largest mixture
+template <int DT>
+static hipError_t launch_refine_wide(const GmmRefineArgs& a, hipStream_t stream) {
+  if (a.n_slots != 32) return hipErrorInvalidValue;
+  if (a.chunks == 2) return launch_refine_one<DT, 32, 4, 2, kRThreadsWide>(a, stream);
+  if (a.chunks == 4) return launch_refine_one<DT, 32, 4, 4, kRThreadsWide>(a, stream);
+  return launch_refine_one<DT, 32, 4, 1, kRThreadsWide>(a, stream);
+}
+
+// a.dim = the PADDED dimension (gmm_refine_padded_dim); a.feats rows of a.dim floats, a.featsT a.dim rows, a.rows 2 a.dim + 2 planes
 hipError_t launch_gmm_refine(const GmmRefineArgs& a, hipStream_t stream) {
   if (a.n_frames == 0) return hipSuccess;
   if (!a.ring || (uint64_t)a.dim * a.n_frames_ld * 4u >= (1ull << 32)) return hipErrorInvalidValue;  // (buffer offsets are 32 bit)
-  const bool eight = refine_spw(a) == 8;
   if (a.chunks != 1 && (a.n_slots != 32 || (a.chunks != 2 && a.chunks != 4))) return hipErrorInvalidValue;
-  switch (a.n_slots) {
-    case 8: return launch_refine_ns<8, 8>(a, stream);
-    case 16: return launch_refine_ns<16, 8>(a, stream);
-    case 32:
-      // (a mixture of more than 32 densities always has 32-slot panels)
-      if (a.chunks == 2) return eight ? launch_refine_ns<32, 8, 2>(a, stream) : launch_refine_ns<32, 4, 2>(a, stream);
-      if (a.chunks == 4) return eight ? launch_refine_ns<32, 8, 4>(a, stream) : launch_refine_ns<32, 4, 4>(a, stream);
-      return eight ? launch_refine_ns<32, 8>(a, stream) : launch_refine_ns<32, 4>(a, stream);
+  switch (a.dim) {
+    case 9: return launch_refine_narrow<9>(a, stream);
+    case 17: return launch_refine_narrow<17>(a, stream);
+    case 25: return launch_refine_narrow<25>(a, stream);
+    case 33: return launch_refine_narrow<33>(a, stream);
+    case 39: return launch_refine_narrow<39>(a, stream);
+    case 47:  // 161 registers: still three waves per SIMD (768 threads), but 4 states per workgroup (8 do not fit the LDS)
+      if (a.n_slots != 32) return hipErrorInvalidValue;
+      return a.chunks == 2 ? launch_refine_one<47, 32, 4, 2, kRThreads>(a, stream) : a.chunks == 4 ? launch_refine_one<47, 32, 4, 4, kRThreads>(a, stream)
+                           : launch_refine_one<47, 32, 4, 1, kRThreads>(a, stream);
+    case 55: return launch_refine_wide<55>(a, stream);
+    case 63: return launch_refine_wide<63>(a, stream);
     default: return hipErrorInvalidValue;
   }
 }

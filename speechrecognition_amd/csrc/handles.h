@@ -104,7 +104,8 @@ struct sr_model {
   int pf_ks32 = 0;
   uint32_t pf_groups = 0, pf_ny = 0, max_dens = 0, pf_slots = 0, pf_chunks = 1, pf_pstates = 0;
   DevBuf<unsigned char> pf_apack;
-  DevBuf<float> pf_anorm, featsT;
+  DevBuf<float> pf_anorm, featsT, featsP;  // featsP: row-major features in the refinement's padded order (only when pf_dp != dim)
+  uint32_t pf_dp = 0;                      // gmm_refine_padded_dim(dim): the odd dimension the refinement planes / featsT are laid out in
   DevBuf<uint32_t> pf_mask, pf_ndens, pf_ring;
   DevBuf<double> pf_rows;
   DevBuf<unsigned long long> pf_counter;

@@ -66,7 +66,9 @@ struct GmmPrefilterArgs {
   uint32_t chunks;              // 1, 2 or 4 consecutive state slots (of 32 densities) make up one state
 };
 struct GmmRefineArgs {
-  const float* feats;           // [n_frames x dim] row-major features (batches of unrelated frames)
+  // dim = the PADDED, odd dimension gmm_refine_padded_dim(model dimension): pair dimensions, zeros, the odd tail last (gmm_prefilter.hip)
+  const float* feats;           // [n_frames x dim] row-major features in that order (batches of unrelated frames): the corpus' own
+                                // rows when its dimension IS dim, else the padded copy launch_transpose_feats writes
   const float* featsT;          // [dim x n_frames_ld] transposed features (main pass: 64 consecutive frames per wave)
   uint64_t n_frames, n_frames_ld;
   uint32_t dim, n_pstates, chunks;  // pseudo-states = states x chunks (a state of up to 32*chunks densities)
@@ -85,11 +87,15 @@ hipError_t launch_gmm_prefilter(const GmmPrefilterArgs& a, int ks32, hipStream_t
 int gmm_prefilter_frames_per_tile();
 // does the fp16 MFMA keep subnormal inputs on this device / in this build (an assumption of the prefilter's error bound)?
 hipError_t probe_fp16_denormals(hipStream_t stream, bool* preserved);
-// does the fp16 MFMA chain accumulate within the bound's model (|error| <= 87 * 2^-24 * sum |a_k b_k| on adversarial dot products)?
-hipError_t probe_fp16_accumulation(hipStream_t stream, bool* ok, double* worst_ratio);
-int gmm_refine_slots(uint32_t max_dens);
+// does the fp16 MFMA chain accumulate within the bound's model (|error| <= 87 (K = 96: ks32 3) / 132 (K = 128: ks32 4) * 2^-24 *
+// sum |a_k b_k| on adversarial dot products)?
+hipError_t probe_fp16_accumulation(hipStream_t stream, int ks32, bool* ok, double* worst_ratio);
+uint32_t gmm_refine_padded_dim(uint32_t dim);               // odd, >= dim; 0: no refinement instantiation (dim > 62)
+int gmm_refine_slots(uint32_t max_dens, uint32_t padded_dim);  // density slots per panel: 8, 16 or 32 (always 32 beyond padded dimension 39)
 hipError_t launch_gmm_refine(const GmmRefineArgs& a, hipStream_t stream);
-hipError_t launch_transpose_feats(const float* feats, uint64_t n_frames, uint32_t dim, uint64_t ldT, float* out, hipStream_t stream);
+// featsT [dp x ldT] in the padded order and, when dp != dim, featsP [n_frames x dp] row-major in the same order (else unused)
+hipError_t launch_transpose_feats(const float* feats, uint64_t n_frames, uint32_t dim, uint32_t dp, uint64_t ldT, float* out, float* featsP,
+                                  hipStream_t stream);
 
 // ---- beam Viterbi decoder (viterbi_decode.hip) ---------------------------------------------------
 // Search network flattened to "slots" = (word, position) pairs in (word, position) order, which is

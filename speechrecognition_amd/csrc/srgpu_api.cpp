@@ -133,15 +133,18 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
   for (uint32_t s = 0; s < S; s++) mx = std::max(mx, dens_off[s + 1] - dens_off[s]);
   m->max_dens = std::max(1u, mx);
   m->pf_ks32 = 0;
-  if (!m->max_approx || mx > 128 || 2 * D + 3 > 96) return SR_OK;  // not eligible: callers get the exact kernel
+  const uint32_t DP = gmm_refine_padded_dim(D);  // the odd dimension the refinement runs in (pairs | zeros | odd tail)
+  if (!m->max_approx || mx > 128 || 2 * D + 3 > 128 || DP == 0) return SR_OK;  // not eligible: callers get the exact kernel
+  const int KS = (int)((2 * D + 3 + 31) / 32);
   {
     bool preserved = false;
     HIP_TRY(probe_fp16_denormals(m->s_gmm, &preserved));
     if (!preserved) return SR_OK;  // the bound of gmm_prefilter.hip does not hold with flushed subnormals: exact kernel
     bool accumulates = false;
-    HIP_TRY(probe_fp16_accumulation(m->s_gmm, &accumulates, nullptr));
+    HIP_TRY(probe_fp16_accumulation(m->s_gmm, KS <= 3 ? 3 : 4, &accumulates, nullptr));  // the chain length this model runs
     if (!accumulates) return SR_OK;  // ... nor with an accumulator outside its model
   }
+  m->pf_dp = DP;
   // A mixture of more than 32 densities is cut into Cs = 2 or 4 chunks of 32: the kernels see S*Cs pseudo-states
   // (ps = st*Cs + chunk), the prefilter takes the minimum across a state's chunks, the refinement folds them.
   const uint32_t Cs = mx <= 32 ? 1u : mx <= 64 ? 2u : 4u;
@@ -160,7 +163,11 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
   // FP64 planes for the refinement: [pseudo-state][mu_0 | 1/var_0 | ... | norm | logw][density slot]; 1 KB of slack
   // for the LDS-DMA's last piece
   {
-    const uint32_t NS = (uint32_t)gmm_refine_slots(std::min(32u, m->max_dens)), planes = 2 * D + 2;
+    const uint32_t NS = (uint32_t)gmm_refine_slots(std::min(32u, m->max_dens), DP), planes = 2 * DP + 2;
+    // padded plane order (gmm_refine_kernel): dimensions 0 .. D - D % 2 - 1 in place, zero planes, an odd D's last dimension in slot
+    // DP - 1; a zero plane pair (mean 0, inverse variance 0) contributes +0.0 to the sums
+    const uint32_t pairs = D - (D & 1u);
+    auto slot_of = [&](uint32_t d) -> uint32_t { return d < pairs ? d : DP - 1u; };
     m->pf_slots = NS;
     // (the packings are built on first use of their kernel: on 16 host threads, a new model's first prefilter call was 170 ms)
     const size_t n_rows_d = (size_t)PS * planes * NS + 128;
@@ -177,15 +184,14 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
         // instruction mixed states; since round 2 every wave instruction evaluates candidates of ONE state, so lanes on
         // different densities hit different bank pairs and lanes on the same density share a broadcast read as it is)
         const uint32_t sl = i;
-        for (uint32_t d = 0; d < D; d++) { r[(2 * d) * NS + sl] = means[c * D + d]; r[(2 * d + 1) * NS + sl] = inv_vars[c * D + d]; }
-        r[(2 * D) * NS + sl] = norm[c];
-        r[(2 * D + 1) * NS + sl] = logw[c];
+        for (uint32_t d = 0; d < D; d++) { r[(2 * slot_of(d)) * NS + sl] = means[c * D + d]; r[(2 * slot_of(d) + 1) * NS + sl] = inv_vars[c * D + d]; }
+        r[(2 * DP) * NS + sl] = norm[c];
+        r[(2 * DP + 1) * NS + sl] = logw[c];
       }
     }
     });
     HIP_TRY(m->pf_rows.upload(rows_p, n_rows_d));
   }
-  const int KS = (int)((2 * D + 3 + 31) / 32);
   const uint32_t n_groups = (PS + 3) / 4;
   const float finf = std::numeric_limits<float>::infinity();
   // per density: coefficients a = [1/(2 var); -mu/var] and the constant
@@ -372,12 +378,14 @@ int reserve_scoring(sr_model* m, int gmm_kernel, uint64_t n_max) {
   }
   if (gmm_kernel == SR_GMM_PREFILTER && m->pf_ks32 > 0 && n_max > 0) {
     const uint64_t ldT = (n_max + 63) & ~(uint64_t)63;
-    const size_t want_T = (size_t)ldT * m->dim, want_mask = (size_t)((m->pf_groups + 1u) & ~1u) * n_max * 4;
+    const size_t want_T = (size_t)ldT * m->pf_dp, want_mask = (size_t)((m->pf_groups + 1u) & ~1u) * n_max * 4;
+    const size_t want_P = m->pf_dp != m->dim ? (size_t)n_max * m->pf_dp + 4 : 0;  // (+4: the rows are read in 16-byte pieces)
     GmmRefineArgs ra{};
-    ra.n_frames = n_max; ra.dim = m->dim; ra.n_pstates = m->pf_pstates; ra.n_slots = m->pf_slots;
+    ra.n_frames = n_max; ra.dim = m->pf_dp; ra.n_pstates = m->pf_pstates; ra.n_slots = m->pf_slots;
     const size_t want_ring = gmm_refine_ring_words(ra);
-    if (want_T > m->featsT.n || want_mask > m->pf_mask.n || want_ring > m->pf_ring.n) HIP_TRY(hipStreamSynchronize(m->s_gmm));
+    if (want_T > m->featsT.n || want_P > m->featsP.n || want_mask > m->pf_mask.n || want_ring > m->pf_ring.n) HIP_TRY(hipStreamSynchronize(m->s_gmm));
     HIP_TRY(m->featsT.ensure(want_T));
+    if (want_P) HIP_TRY(m->featsP.ensure(want_P));
     HIP_TRY(m->pf_mask.ensure(want_mask));  // the refinement reads group pairs
     HIP_TRY(m->pf_ring.ensure(want_ring));
   }
@@ -416,7 +424,9 @@ int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm
     pa.apack = m->pf_apack.p; pa.grp_anorm = m->pf_anorm.p; pa.split_begin = m->pf_split_cur;
     pa.mask = m->pf_mask.p; pa.nx = nx; pa.ny = m->pf_ny; pa.chunks = m->pf_chunks;
     GmmRefineArgs ra{};
-    ra.feats = d_feats; ra.featsT = m->featsT.p; ra.n_frames = n_frames; ra.n_frames_ld = ldT; ra.dim = m->dim; ra.n_pstates = m->pf_pstates; ra.chunks = m->pf_chunks;
+    const bool padded = m->pf_dp != m->dim;
+    ra.feats = padded ? m->featsP.p : d_feats; ra.featsT = m->featsT.p; ra.n_frames = n_frames; ra.n_frames_ld = ldT; ra.dim = m->pf_dp;
+    ra.n_pstates = m->pf_pstates; ra.chunks = m->pf_chunks;
     ra.n_dens_ps = m->pf_ndens.p; ra.rows = m->pf_rows.p; ra.n_slots = m->pf_slots;
     ra.mask = m->pf_mask.p; ra.out = d_out; ra.ld = m->ld;
     ra.n_refined = m->profiling ? m->pf_counter.p : nullptr;
@@ -425,7 +435,7 @@ int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm
     EventPair ep_p{}, ep_r{};
     if ((rc = prof_begin(m, m->s_gmm, 0, &ep))) return rc;
     if ((rc = prof_begin(m, m->s_gmm, 2, &ep_p))) return rc;
-    HIP_TRY(launch_transpose_feats(d_feats, n_frames, m->dim, ldT, m->featsT.p, m->s_gmm));
+    HIP_TRY(launch_transpose_feats(d_feats, n_frames, m->dim, m->pf_dp, ldT, m->featsT.p, padded ? m->featsP.p : nullptr, m->s_gmm));
     HIP_TRY(launch_gmm_prefilter(pa, m->pf_ks32, m->s_gmm));
     if ((rc = prof_end(m, m->s_gmm, &ep_p))) return rc;
     if ((rc = prof_begin(m, m->s_gmm, 3, &ep_r))) return rc;
@@ -433,7 +443,7 @@ int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm
     if ((rc = prof_end(m, m->s_gmm, &ep_r))) return rc;
     if ((rc = prof_end(m, m->s_gmm, &ep))) return rc;
   } else if (gmm_kernel == SR_GMM_EXACT || gmm_kernel == SR_GMM_PREFILTER) {
-    // (a model the prefilter cannot take -- sum scoring, > 128 densities per mixture, dim > 46, or a device that fails
+    // (a model the prefilter cannot take -- sum scoring, > 128 densities per mixture, dim > 62, or a device that fails
     // the fp16 probes -- is scored by the exact kernel: same bits, FP64 VALU speed)
     GmmExactArgs a{};
     a.feats = d_feats; a.n_frames = n_frames; a.dim = m->dim; a.n_states = m->n_states;
@@ -1628,11 +1638,12 @@ int sr_probe_fp16_accumulation(int device, int* within_model, double* worst_rati
   return guarded(__func__, [&]() -> int {
   if (!within_model) return fail(SR_EINVAL, "within_model is null");
   HIP_TRY(hipSetDevice(device));
-  bool ok = false;
-  double worst = 0.0;
-  HIP_TRY(probe_fp16_accumulation(nullptr, &ok, &worst));
-  *within_model = ok ? 1 : 0;
-  if (worst_ratio) *worst_ratio = worst;
+  bool ok = false, ok4 = false;
+  double worst = 0.0, worst4 = 0.0;
+  HIP_TRY(probe_fp16_accumulation(nullptr, 3, &ok, &worst));    // K = 96: models of dimension <= 46
+  HIP_TRY(probe_fp16_accumulation(nullptr, 4, &ok4, &worst4));  // K = 128: dimension 47 .. 62 (allowed: 132)
+  *within_model = (ok && ok4) ? 1 : 0;
+  if (worst_ratio) *worst_ratio = std::max(worst, worst4 * (87.0 / 132.0));  // on the K = 96 scale
   return SR_OK;
   });
 }

@@ -539,8 +539,8 @@ __global__ __launch_bounds__(kBgThreads) void bigram_kernel(BigramArgs a) {
         const uint32_t fl = pinfo[q] >> 16, sl = pslot[q];
         const bool sil_ = (fl >> 3) & 1u, in = j < P2;
         // the dense layout is where a silence word of SEVERAL states lands (bigram_register_layout requires one): inside silence
-        // and its copies all three silence penalties apply, tdp[isSilence][s' - s] (LinearSearch.cc:296-326; oracle/sr_oracle.c
-        // orc_bigram_decode).  Only the register layout above may treat forward and skip as the words' scalars.
+        // and its copies all three silence penalties apply, tdp[isSilence][s' - s] (LinearSearch.cc:296-326).  Only the register
+        // layout above may treat forward and skip as the words' scalars.
         const float t0 = sil_ ? a.tdp[1][0] : a.tdp[0][0], t1 = sil_ ? a.tdp[1][1] : a.tdp[0][1], t2 = sil_ ? a.tdp[1][2] : a.tdp[0][2];
         const float inf = __builtin_inff();
         // states 1 and 2 are reachable from the virtual entry state 0: free to state 1, skip penalty to state 2

@@ -234,6 +234,14 @@ def sample_utterance(spec: MixsetSpec, lex: LexiconSpec, words, seed=3, frames_p
     return np.asarray(frames, dtype=np.float32)
 
 
+def scale_variances(spec: MixsetSpec, factor: float):
+    """Multiplies every variance by `factor` in place (the accumulators keep their means): tight variances (0.004) give negative
+    emission costs, the case the reference's pre-AM early-out is live in (Recognizer.cpp:143,173)."""
+    mu_v = spec.mean_acc[spec.dens_mean] / spec.mean_w[spec.dens_mean][:, None]      # per density: its mean
+    var = spec.var_acc[spec.dens_var] / spec.var_w[spec.dens_var][:, None] - mu_v ** 2
+    spec.var_acc[spec.dens_var] = (factor * var + mu_v ** 2) * spec.var_w[spec.dens_var][:, None]
+
+
 def write_config(path, mixset_path, tdp=(3.0, 0.0, 30.0), am_threshold=200.0, word_penalty=10.0, extra=None):
     """JSON config for the reference classes (double parameters need a decimal point,
     sietill/Config.cpp:114-126; verbosity must be set, Mixtures.cpp:150,164)."""

@@ -481,12 +481,26 @@ def test_em_iteration_matches_reference_model_file(tmp_path, oracle_lib):
     (909, 13, 64, 39, 1.0, 0.5, False),     # 64 (BASELINE configs[4] mixtures), odd state count
     (910, 11, (1, 100), 25, 1.0, 0.5, False),  # ragged up to 100 densities: four chunks, some of them empty
     (911, 6, 130, 12, 1.0, 0.5, False),     # 130 densities: not eligible -> exact kernel, same bits
-    (908, 16, 4, 47, 1.0, 0.5, False),      # dim 47: not eligible either
+    (908, 16, 4, 63, 1.0, 0.5, False),      # dim 63 (K = 129): not eligible either
     (912, 9, 64, 39, 1.0, 0.5, True),       # round 4 (one evaluation per STATE): exact ties ACROSS a state's two chunks
     (913, 7, (33, 128), 39, 1.0, 0.5, True),  # three / four chunks at dim 39, ties across chunks, non-finite frames below
+    # round 5: every dimension <= 62 on the prefilter path -- the refinement runs in a padded odd dimension (9, 17, 25, 33, 39 on 768
+    # threads; 47, 55, 63 on 512), the fp16 pass with four k-steps (K = 128) from dimension 47
+    (920, 20, 8, 1, 1.0, 0.5, False),       # dim 1: no pair at all, only the odd tail          (padded 9)
+    (921, 20, 8, 2, 1.0, 0.5, True),        # dim 2: one pair, empty tail
+    (922, 24, 16, 13, 1.0, 0.5, False),     # dim 13 -> padded 17 (odd: tail moves to slot 16)
+    (923, 24, 32, 26, 1.0, 0.5, True),      # dim 26 -> padded 33 (even: empty tail)
+    (924, 24, 32, 33, 1.0, 0.5, False),     # dim 33: exact fit
+    (925, 24, 32, 38, 1.0, 0.5, False),     # dim 38 -> padded 39, empty tail
+    (926, 24, 32, 40, 1.0, 0.5, True),      # dim 40 -> padded 47, 512 threads, K = 83
+    (927, 21, 8, 45, 1.0, 0.5, False),      # dim 45 -> 47, small mixtures in 32-slot panels
+    (928, 24, 32, 47, 1.0, 0.5, False),     # dim 47: K = 97 -> four k-steps
+    (929, 13, (1, 70), 50, 1.0, 0.5, True),  # dim 50 -> 55, up to three chunks, ties across chunks, non-finite frames
+    (930, 24, 32, 62, 3.0, 0.5, False),     # dim 62 (K = 127, the limit) -> 63, features far from the means
+    (931, 9, 128, 61, 1.0, 1e-3, True),     # dim 61 -> 63 (odd tail in slot 62), four full chunks, small variances
 ])
 def test_prefilter_scores_are_bit_identical(tmp_path, oracle_lib, seed, S, M, D, scale, var_floor, dup):
-    """SR_GMM_PREFILTER must return MixtureModel::score's bits: the bf16 stage may only over-select candidates."""
+    """SR_GMM_PREFILTER must return MixtureModel::score's bits: the fp16 stage may only over-select candidates."""
     rng = np.random.default_rng(seed)
     nm = M if np.isscalar(M) else rng.integers(M[0], M[1] + 1, size=S)
     spec = synth.make_mixset(S, nm, D, seed=seed, var_floor=var_floor)
@@ -506,7 +520,7 @@ def test_prefilter_scores_are_bit_identical(tmp_path, oracle_lib, seed, S, M, D,
     feats[5] = 0.0
     feats[6] = 1e-20     # squares underflow in bf16/fp32
     feats[7, 0] = 250.0  # one dominant component
-    if seed >= 912:      # every density of every chunk stays a candidate: all lists, both levels, all chunks
+    if seed in (912, 913, 929, 931):  # every density of every chunk stays a candidate: all lists, both levels, all chunks
         feats[9] = np.nan
         feats[10, 3] = np.inf
         feats[11, 1] = 1e30
@@ -515,10 +529,16 @@ def test_prefilter_scores_are_bit_identical(tmp_path, oracle_lib, seed, S, M, D,
     want = o.score_matrix(feats)
     o.close()
     with capi.Model.from_mixset(mp, D) as m:
+        m.profile(True)
         got = m.score_frames(feats, capi.GMM_PREFILTER)
+        prof = m.profile_read()
+        m.profile(False)
         exact = m.score_frames(feats, capi.GMM_EXACT)
     assert np.array_equal(exact.view(np.uint64), want.view(np.uint64))
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    # which kernels produced `got`: the fp16 pass + refinement for every eligible model, the exact kernel otherwise
+    eligible = D <= 62 and int(np.max(nm)) <= 128
+    assert (prof["prefilter_ms"] > 0 and prof["refined_densities"] >= T * S) == eligible, prof
 
 
 def test_prefilter_full_size_matches_exact_kernel(tmp_path):
@@ -633,7 +653,7 @@ def test_handles_give_their_device_memory_back(tmp_path):
     assert free[-1] >= free[2] - (1 << 20), free  # (the first iterations warm up runtime pools)
 
 
-@pytest.mark.parametrize("S,M,D", [(24, 16, 39), (13, 64, 39), (9, 8, 25)])
+@pytest.mark.parametrize("S,M,D", [(24, 16, 39), (13, 64, 39), (9, 8, 25), (12, 32, 47), (9, 16, 62), (10, 8, 6)])
 def test_prefilter_overflow_and_nonfinite_features(tmp_path, oracle_lib, S, M, D):
     """Features the fp16 stage cannot represent: |x| = 256 and 300 (the square leaves fp16's range: inf), 1e4, 7e4 (x itself
     does), +-inf and NaN.  Their frames' prefilter scores are inf/NaN, every density stays a candidate, and the FP64 stage
@@ -655,10 +675,16 @@ def test_prefilter_overflow_and_nonfinite_features(tmp_path, oracle_lib, S, M, D
     want = o.score_matrix(feats)
     o.close()
     with capi.Model.from_mixset(mp, D) as m:
+        m.profile(True)
         got = m.score_frames(feats, capi.GMM_PREFILTER)
+        prof = m.profile_read()
+        m.profile(False)
         exact = m.score_frames(feats, capi.GMM_EXACT)
     assert np.array_equal(exact.view(np.uint64), want.view(np.uint64))
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    # which kernels produced `got`: the fp16 pass + refinement for every eligible model, the exact kernel otherwise
+    eligible = D <= 62 and M <= 128
+    assert (prof["prefilter_ms"] > 0 and prof["refined_densities"] >= T * S) == eligible, prof
     assert np.all(want[40 + specials.index(np.nan)] == 1e10)  # an all-NaN frame: every state keeps min_score's seed
 
 

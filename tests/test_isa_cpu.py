@@ -121,8 +121,12 @@ __global__ void racy(double* out, const double* in) {
 # kernel (as tools/isa_info.py prints it) -> most VGPRs its launch geometry allows
 VGPR_BUDGET = {
     # 768 threads = 3 waves per SIMD: 512 / 3 -> 168 (allocation granule 8)
-    "gmm_refine_kernel<39, 32, 8, 1>": 168, "gmm_refine_kernel<39, 32, 8, 2>": 168, "gmm_refine_kernel<39, 32, 8, 4>": 168,
-    "gmm_refine_kernel<39, 8, 8, 1>": 168, "gmm_refine_kernel<39, 16, 8, 1>": 168,
+    "gmm_refine_kernel<39, 32, 8, 1, 768>": 168, "gmm_refine_kernel<39, 32, 8, 2, 768>": 168, "gmm_refine_kernel<39, 32, 8, 4, 768>": 168,
+    "gmm_refine_kernel<39, 8, 8, 1, 768>": 168, "gmm_refine_kernel<39, 16, 8, 1, 768>": 168, "gmm_refine_kernel<33, 32, 8, 1, 768>": 168,
+    "gmm_refine_kernel<47, 32, 4, 1, 768>": 168, "gmm_refine_kernel<47, 32, 4, 2, 768>": 168, "gmm_refine_kernel<47, 32, 4, 4, 768>": 168,
+    # padded dimension 55 / 63: 512 threads = 2 waves per SIMD
+    "gmm_refine_kernel<55, 32, 4, 2, 512>": 256, "gmm_refine_kernel<63, 32, 4, 1, 512>": 256,
+    "gmm_refine_kernel<63, 32, 4, 4, 512>": 256, "gmm_prefilter16_kernel<4, 4>": 256,
     # 256 threads, two workgroups per CU = 2 waves per SIMD
     "gmm_prefilter16_kernel<3, 4>": 256,
     # 8 waves per workgroup, two workgroups per CU = 4 waves per SIMD
@@ -130,8 +134,9 @@ VGPR_BUDGET = {
     # 1024 threads = 4 waves per SIMD (configs[4]'s lexicon: three-state rows 0 and 1, the four-state word in row 2)
     "bigram_kernel<3, 4, 3, 4>": 128, "bigram_kernel<3, 4, 3, 0>": 128,
 }
-NO_SCRATCH = ("gmm_refine_kernel<39, 32, 8, 1>", "gmm_refine_kernel<39, 32, 8, 2>", "gmm_refine_kernel<39, 8, 8, 1>",
-              "gmm_prefilter16_kernel<3, 4>", "decode_words_kernel<3, 3, false>", "decode_words_kernel<1, 3, false>",
+NO_SCRATCH = ("gmm_refine_kernel<39, 32, 8, 1, 768>", "gmm_refine_kernel<39, 32, 8, 2, 768>", "gmm_refine_kernel<39, 8, 8, 1, 768>",
+              "gmm_refine_kernel<63, 32, 4, 1, 512>", "gmm_refine_kernel<47, 32, 4, 2, 768>", "gmm_refine_kernel<9, 32, 8, 1, 768>",
+              "gmm_prefilter16_kernel<3, 4>", "gmm_prefilter16_kernel<4, 4>", "decode_words_kernel<3, 3, false>", "decode_words_kernel<1, 3, false>",
               "bigram_kernel<3, 4, 3, 4>", "bigram_kernel<3, 4, 3, 0>")  # (round 4: the bigram search lost its last vector spills)
 
 

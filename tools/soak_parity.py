@@ -4,7 +4,7 @@ usage: python tools/soak_parity.py [n_cases] [seed] [ragged|short] [--ledger FIL
 (ragged: synth.make_ragged_lexicon instead of the uniform lexicon; short: words of one to four positions -- the word-per-lane search
 kernel, cross-checked against the slot-per-lane kernel.)  --ledger appends ONE JSON line per run -- seed, generator, cases run, the
 first failing case if any, wall time, the commit and kernel-source hash of the library under test -- to FILE; the lines judged are
-kept under profiles/r4_soak.jsonl."""
+kept under profiles/r4_soak.jsonl, profiles/r5_soak.jsonl."""
 import json, os, sys, tempfile, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -28,7 +28,7 @@ def run_case(case, seed0=0, ragged=False, tmp=None):
     reps = int(rng.integers(1, 3))
     if spw * reps < 2:
         reps = 2  # (the decoder wants a word with two or more positions: sr_lexicon_create's documented limit)
-    D = int(rng.choice([4, 12, 25, 39, 46, 50]))
+    D = int(rng.choice([1, 4, 12, 25, 26, 33, 39, 40, 46, 47, 50, 62, 63]))  # (round 5: every dimension <= 62 on the prefilter path; 63: exact kernel)
     Mhi = int(rng.choice([1, 3, 8, 33, 70, 100]))  # (33 / 70 / 100: two, three and four 32-slot chunks per state in the refinement)
     if W >= 1000:
         Mhi = min(Mhi, 3)
