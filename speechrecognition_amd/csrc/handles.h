@@ -105,6 +105,7 @@ struct sr_model {
   uint32_t pf_groups = 0, pf_ny = 0, max_dens = 0, pf_slots = 0, pf_chunks = 1, pf_pstates = 0;
   DevBuf<unsigned char> pf_apack;
   DevBuf<float> pf_anorm, featsT, featsP;  // featsP: row-major features in the refinement's padded order (only when pf_dp != dim)
+  int neg_possible = -1;                   // can an emission cost of this model be negative?  -1: not looked at yet (srhost::may_go_negative)
   uint32_t pf_dp = 0;                      // gmm_refine_padded_dim(dim): the odd dimension the refinement planes / featsT are laid out in
   DevBuf<uint32_t> pf_mask, pf_ndens, pf_ring;
   DevBuf<double> pf_rows;
@@ -196,6 +197,7 @@ namespace srhost {
 // (srgpu_api.cpp) handle without parameter tables / lazily fetched host copies of them
 int model_shell(int device, uint32_t dim, uint32_t n_states, const uint32_t* dens_off, int max_approx, sr_model** out);
 int ensure_host_tables(sr_model* m);
+int may_go_negative(sr_model* m, bool* out);  // can an emission cost of this model be negative or NaN? (cached)
 // (em_finalize.hip) MixtureModel::finalize on the device: statistics (host arrays) -> new model whose tables are built in HBM
 int finalize_on_device(int device, uint32_t dim, uint32_t n_states, const uint32_t* dens_off, uint32_t n_mean, uint32_t n_var,
                        const uint32_t* dens_mean, const uint32_t* dens_var, const double* mean_acc, const double* mean_w,

@@ -154,6 +154,8 @@ struct DecodeArgs {
   uint32_t force_general;       // skip the fast kernels: every utterance goes through decode_kernel<.., REPLAY = true>
   uint32_t force_slots;         // the slot-per-lane kernel (viterbi_fast.hip) even where the word-per-lane kernel applies
   uint32_t only_flagged;        // decode_big_kernel as the replay of the word-per-lane kernel: only utterances flagged kFlagReplay
+  uint32_t exact_negative;      // the model's emission costs can be negative (some density has norm - log weight < 0): the word-per-lane kernel
+                                // runs its NEG variant, which replays the reference's early-out instead of flagging the utterance
 };
 hipError_t launch_decode(const DecodeArgs& a, hipStream_t stream);       // fast variant, then the replay variant for flagged utterances
 hipError_t launch_decode_fast(const DecodeArgs& a, hipStream_t stream);

@@ -671,6 +671,42 @@ int ensure_host_tables(sr_model* m) {
   return SR_OK;
 }
 
+// Can an emission cost of this model be negative (or not a number)?  The search kernels' collapsed word-boundary transition rests on
+// costs >= 0 (Recognizer.cpp:143,173: the early-out is inert then); a model that can break it is searched by the variant that replays
+// the early-out (viterbi_words.hip, NEG) instead of being flagged utterance by utterance.  A density's score is
+// fl(fl(norm + dist / 2) - logw) with dist >= 0 whenever every inverse variance is >= 0, and rounding is monotone, so
+// fl(norm - logw) >= 0 for every density rules negative costs out (a variance <= 0 or NaN makes norm -inf or NaN: caught).  Sum
+// scoring (Mixtures.cpp:719-728) lies up to log(#densities) below the smallest density score.
+int may_go_negative(sr_model* m, bool* out) {
+  if (m->neg_possible < 0) {
+    const size_t C = m->n_dens;
+    std::vector<double> norm_l, logw_l;
+    const double *norm = m->h_norm.data(), *logw = m->h_logw.data();
+    if (m->h_norm.size() != C || m->h_logw.size() != C) {
+      norm_l.resize(C); logw_l.resize(C);
+      if (C) {
+        HIP_TRY(hipMemcpy(norm_l.data(), m->norm.p, C * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(logw_l.data(), m->logw.p, C * sizeof(double), hipMemcpyDeviceToHost));
+      }
+      norm = norm_l.data(); logw = logw_l.data();
+    }
+    bool neg = false;
+    for (uint32_t s = 0; s < m->n_states && !neg; s++) {
+      const uint32_t c0 = m->h_dens_off[s], c1 = m->h_dens_off[s + 1];
+      const double slack = m->max_approx ? 0.0 : std::log((double)std::max(1u, c1 - c0)) + 1e-6;
+      for (uint32_t c = c0; c < c1; c++)
+        if (!(norm[c] - logw[c] - slack >= 0.0)) { neg = true; break; }
+    }
+    // tables handed in through sr_model_create are taken as they are: a negative or NaN inverse variance there
+    if (!neg && m->h_inv_vars.size() == C * (size_t)m->dim)
+      for (double iv : m->h_inv_vars)
+        if (!(iv >= 0.0)) { neg = true; break; }
+    m->neg_possible = neg ? 1 : 0;
+  }
+  *out = m->neg_possible == 1;
+  return SR_OK;
+}
+
 }  // namespace srhost
 
 extern "C" {
@@ -1089,6 +1125,11 @@ int sr_recognize_corpus(sr_model* m, sr_corpus* c, sr_lexicon* l, const sr_searc
   if (p->flags & ~(SR_SEARCH_GENERAL_KERNEL | SR_SEARCH_SLOT_KERNEL)) return fail(SR_EINVAL, "unknown sr_search_params.flags 0x%x", (unsigned)p->flags);
   da.force_general = (p->flags & SR_SEARCH_GENERAL_KERNEL) ? 1u : 0u;
   da.force_slots = (p->flags & SR_SEARCH_SLOT_KERNEL) ? 1u : 0u;
+  {
+    bool neg = false;
+    if ((rc = srhost::may_go_negative(m, &neg))) return rc;
+    da.exact_negative = neg ? 1u : 0u;
+  }
   da.tb_score = c->tb_score.p; da.tb_word = c->tb_word.p; da.tb_bkp = c->tb_bkp.p;
   da.out_words = c->out_words.p; da.out_count = c->out_count.p; da.out_flags = c->out_flags.p;
 

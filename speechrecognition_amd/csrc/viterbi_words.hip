@@ -26,8 +26,25 @@
 // Recognizer.cpp:143,173, is inert then); an utterance that breaks it is flagged kFlagReplay and redone by
 // decode_kernel<.., REPLAY = true>.  Results are bit-identical to the slot kernel, the general kernel and the oracle; tie
 // order is the reference's hypothesis index word * max_pos + pos, which orders like word_off[word] + pos.
+//
+// NEG = true (round 5): the same kernel WITHOUT that premise, for models whose emission costs can be negative (the host decides from
+// the model: some density has norm - log weight < 0).  The early-out compares a candidate BEFORE its emission cost with the target's
+// value AFTER it: with a negative cost a candidate that would have won can be skipped, and what a slot ends up with depends on the
+// order of its candidates.  Three things replace the fast formulas, frame by frame and only where needed:
+//   * positions >= 2 make their three offers (skip, forward, loop) through Merge::offer, the reference's own test, always;
+//   * positions 0 and 1 (and a one-position word's dead position-1 slot) keep the collapsed boundary candidate while the word's
+//     entry emission costs are >= 0 (exact then, see above);
+//   * where an entry emission cost is negative or not a number, the lane replays the boundary loop (Recognizer.cpp:133-158) for its
+//     word against the surviving word ends of the previous frame in hypothesis order: word ends of the words before it, its own
+//     in-word sources, the remaining word ends.  The word-end scores sit in a dense per-word LDS array (written unpruned in phase A,
+//     double buffered by frame parity, the previous frame's prune limit applied while reading); a wave scans it 64 words per read,
+//     ballots the live ones and visits only those -- O(W / 64 + live word ends) per affected wave and frame instead of the general
+//     kernel's O(W) per lane on top of a five times heavier frame (220 ms against 2 ms on configs[2]'s lexicon with tight variances,
+//     profiles/r5_cliffs.txt).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "dpp_util.h"
 #include "kernels.h"
@@ -55,8 +72,27 @@ static constexpr uint32_t kWordsCellBytes = 1024;  // minima and first-index cel
 // is +inf without a select.
 enum : uint32_t { kGSkip = 0, kGPlain = 1, kGSingle = 2, kGGeneral = 3 };
 
-template <int NW, int L, bool GEN>
-__global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
+// one target hypothesis being built, candidates offered in the reference's source order (Recognizer.cpp:143-157 / :173-186): the
+// early-out on the candidate BEFORE its emission cost, then strict improvement
+struct WMerge {
+  double score;
+  uint32_t bkp;
+  __device__ WMerge() : score(kInfF), bkp(0) {}
+  __device__ void offer(double pre_am, double am, uint32_t cand_bkp) {
+    const double n = pre_am + am;
+    const bool take = !(pre_am > score) && (score > n);
+    score = take ? n : score;
+    bkp = take ? cand_bkp : bkp;
+  }
+};
+__device__ inline double readlane_d(double v, uint32_t l) {  // l wave-uniform
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), (int)l), __builtin_amdgcn_readlane(__double2loint(v), (int)l));
+}
+
+// MAXT: the launch bound.  1024 (128 registers: two workgroups of <= 8 waves per CU) for the fast variant; the NEG variant's word-end
+// arrays leave room for one workgroup per CU only, so with <= 512 threads it may use 256 registers (no spills).
+template <int NW, int L, bool GEN, bool NEG = false, int MAXT = 1024>
+__global__ __launch_bounds__(MAXT) void decode_words_kernel(DecodeArgs a) {
   constexpr int NPA = GEN ? 4 : L;  // positions a lane keeps per word
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   double* c_best = reinterpret_cast<double*>(smem);                 // [3] block minimum of the frame's new scores, by frame mod 3
@@ -71,6 +107,9 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
   // 1 KB piece, 15 % of a frame at configs[2] (tools/words_stamps_r4.py, profiles/r4_words_stamps.txt)
   const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
   const uint32_t row_bytes = a.ld * 8u, row_pad = (row_bytes + 16u + 1023u) & ~1023u;  // row, then the +inf cell
+  // NEG: word-end score of every word (unpruned, +inf: none), [2] by frame parity, behind the row buffers
+  const uint32_t n_words = a.net.n_words, we_pad = (n_words * 8u + 1023u) & ~1023u;
+  double* we_all = reinterpret_cast<double*>(rows_lds + 2u * row_pad);
 
   const uint32_t u = a.utt_order ? a.utt_order[a.utt_first + blockIdx.x] : a.utt_first + blockIdx.x;
   const uint64_t f0 = a.frame_off[u];
@@ -123,10 +162,15 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
   // from two buffers by issuing the copy right behind the barrier, see the frame loop.)
   if (tid < 2) *reinterpret_cast<double*>(rows_lds + tid * row_pad + row_bytes) = kInfF;
   const bool init_is_end = a.words.init_is_end;
+  if constexpr (NEG) {  // "frame 0": the initial hypothesis (word 0, score 0) is the one word end, if it is one
+    for (uint32_t i = tid; i < 2u * (we_pad >> 3); i += nt) we_all[i] = kInfF;
+  }
   double m_we = init_is_end ? 0.0 : kInfF;  // minimum over the word ends that survived the previous frame (uniform)
   if (tid == 0) { a.tb_score[tb0] = 0.0; a.tb_word[tb0] = 0; a.tb_bkp[tb0] = 0; }
   __syncthreads();
   if (tid < 4 && init_is_end) e_first[tid] = 0;  // "frame 0": the initial hypothesis is a word end of index 0 in every class
+  if (NEG && tid == 0 && init_is_end) we_all[0] = 0.0;  // (buffer 0 = frame 0; published by the barrier below)
+  double limit_prev = kInfF;  // NEG: the previous frame's prune limit (uniform)
 
   const uint32_t n_full = row_bytes >> 10, tail_bytes = row_bytes & 1023u;  // whole 1 KB pieces of a row; what the last, short piece holds
   auto issue_row = [&](uint32_t frame /* 1-based */) {  // row of `frame` -> buffer frame & 1; every wave copies its share of the pieces
@@ -183,6 +227,134 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
       for (int p = 0; p < NPA; p++)
         if ((GEN && k == 0 && kind[k] == kGGeneral) || (kind[k] == kGPlain && p < L) || p == 0) e[k][p] = *reinterpret_cast<const double*>(row_l + st[k][p]);
     }
+    if constexpr (NEG) {
+      // ---- NEG: exact under negative emission costs (file header).  One word of the lane; PLAIN: L positions, no silence flags (every
+      // penalty a scalar); NP = positions compiled in (L, 1 for a group of one-position words, 4 for a general group) -------------
+      const double* we_prev = we_all + ((t - 1u) & 1u) * (we_pad >> 3);
+      double* we_cur = we_all + (t & 1u) * (we_pad >> 3);
+      auto neg_word = [&](auto plain_tag, auto np_tag, const int k) __attribute__((always_inline)) {
+        constexpr bool PLAIN = decltype(plain_tag)::value;
+        constexpr int NP = decltype(np_tag)::value;
+        uint32_t inf_k = info[k];
+        asm volatile("" : "+v"(inf_k));  // (nothing derived from the flags is to be hoisted out of the frame loop: registers)
+        const uint32_t n = PLAIN ? (uint32_t)L : (inf_k & 7u);
+        const bool in = PLAIN ? (bool)((real[k] >> lane) & 1ull) : n != 0u;
+        const bool sil_word = PLAIN ? false : (bool)(inf_k & kWSilWord), first_sil = PLAIN ? false : (bool)(inf_k & kWFirstSil);
+        const double wp_l = sil_word ? 0.0 : wp_word;
+        const double base_we = m_we + wp_l;
+        const double e0 = e[k][0], e1 = NP >= 2 ? e[k][NP >= 2 ? 1 : 0] : 0.0;
+        const double old0 = sc[k][0], old1 = NP >= 2 ? sc[k][NP >= 2 ? 1 : 0] : kInfF;
+        const uint32_t ob0 = bk[k][0], ob1 = NP >= 2 ? bk[k][NP >= 2 ? 1 : 0] : 0u;
+        // positions >= 2: skip, forward, loop in source order through the early-out
+#pragma unroll
+        for (int p = NP - 1; p >= 2; p--) {
+          const bool valid = (uint32_t)p < n, end = (uint32_t)p + 1u == n;
+          const bool sil = PLAIN ? false : (bool)((inf_k >> (8 + p)) & 1u);
+          const double t_loop = sil ? tf : tl, t_skip = sil ? tf : ts;  // TdpModel.cpp:19-29, keyed on the destination state
+          const double ep = e[k][p];
+          WMerge mg;
+          mg.offer(sc[k][p - 2] + t_skip, ep, bk[k][p - 2]);
+          mg.offer(sc[k][p - 1] + tf, ep, bk[k][p - 1]);
+          mg.offer(end ? kInfF : sc[k][p] + t_loop, ep, bk[k][p]);
+          sc[k][p] = valid ? mg.score : kInfF; bk[k][p] = mg.bkp;
+        }
+        // positions 1 and 0: the collapsed boundary candidate, exact while the word's entry emission costs are >= 0
+        const bool sil0 = PLAIN ? false : (bool)((inf_k >> 8) & 1u), sil1 = PLAIN ? false : (bool)((inf_k >> 9) & 1u);
+        const bool end0 = n == 1u, end1 = n == 2u, valid1 = n >= 2u;
+        const double pre_loop0 = end0 ? kInfF : old0 + (sil0 ? tf : tl);
+        const double pre_fwd1 = valid1 ? old0 + tf : kInfF, pre_loop1 = (valid1 && !end1) ? old1 + (sil1 ? tf : tl) : kInfF;
+        const double tb1 = first_sil ? tf : ts;  // tdp(first_state, init + 1): position 1, or the dead slot of a one-position word
+        double v1 = kInfF, dead = kInfF;
+        uint32_t b1 = 0;
+        if (NP >= 2) {
+          v1 = pre_fwd1 + e1; b1 = ob0;
+          const double s0 = pre_loop1 + e1;
+          b1 = s0 < v1 ? ob1 : b1;
+          v1 = dmin(v1, s0);
+          const double n_b = (base_we + tb1) + e0;  // scored with position 0's emission (Recognizer.cpp:136,148-151)
+          tie[k][1] = __ballot(valid1 && n_b == v1) & real[k] & we_in;
+          b1 = n_b < v1 ? bkp_new : b1;
+          v1 = valid1 ? dmin(v1, n_b) : kInfF;
+        }
+        double v0 = pre_loop0 + e0;
+        uint32_t b0 = ob0;
+        {
+          const double n_b = (base_we + tf) + e0;
+          tie[k][0] = __ballot(in && n_b == v0) & real[k] & we_in;
+          b0 = n_b < v0 ? bkp_new : b0;
+          v0 = dmin(v0, n_b);
+          if (!PLAIN) dead = end0 ? (base_we + tb1) + e0 : kInfF;  // feeds best_score only (Recognizer.cpp:139,155)
+          if (!PLAIN && end0) b0 = v0 < kInfF ? bkp_new : 0u;
+        }
+        // ... else the lane replays the boundary loop for its word
+        const bool slow = in && (!(e0 >= 0.0) || (valid1 && !(e1 >= 0.0)));
+        const uint64_t slow_mask = __ballot(slow);
+        if (slow_mask) {  // wave-uniform
+          WMerge m0, m1;  // position 0; position 1 (n >= 2) or the dead slot (n == 1)
+          // ONE pass over the live word ends in hypothesis order; a lane's in-word sources take their turn when the pass reaches the
+          // first word end that is not before the lane's word (a wave-uniform branch, taken once per slow lane at most)
+          bool inword_due = slow;
+          constexpr int kAhead = 8;  // array reads in flight: a dependent LDS round trip per 64 words cost a third of a frame at W = 1334
+#pragma unroll 1
+          for (uint32_t base0 = 0; base0 < n_words; base0 += 64u * kAhead) {
+            double svs[kAhead];
+#pragma unroll
+            for (int j = 0; j < kAhead; j++) {
+              const uint32_t vi = base0 + 64u * j + lane;
+              svs[j] = vi < n_words ? we_prev[vi] : kInfF;
+            }
+#pragma unroll
+            for (int j = 0; j < kAhead; j++) {
+              const double sv = svs[j];
+              const uint32_t base = base0 + 64u * j;
+              uint64_t live = __ballot(sv != kInfF && !(sv > limit_prev));  // the previous frame's survivors (:194-196)
+              while (live) {
+                const uint32_t i = (uint32_t)__builtin_ctzll(live);
+                live &= live - 1ull;
+                const double s_e = readlane_d(sv, i);
+                const uint32_t v = base + i;
+                const bool now = inword_due && v >= word[k];
+                if (__ballot(now)) {  // the in-word sources, ascending, before this word end
+                  m0.offer(now ? pre_loop0 : kInfF, e0, ob0);
+                  m1.offer(now ? pre_fwd1 : kInfF, e1, ob0);
+                  m1.offer(now ? pre_loop1 : kInfF, e1, ob1);
+                  inword_due = inword_due && !now;
+                }
+                const double c = s_e + wp_l;
+                m0.offer(slow ? c + tf : kInfF, e0, bkp_new);
+                m1.offer(slow ? c + tb1 : kInfF, e0, bkp_new);
+              }
+            }
+          }
+          m0.offer(inword_due ? pre_loop0 : kInfF, e0, ob0);  // (no live word end at or behind the lane's word)
+          m1.offer(inword_due ? pre_fwd1 : kInfF, e1, ob0);
+          m1.offer(inword_due ? pre_loop1 : kInfF, e1, ob1);
+          if (slow) {
+            v0 = m0.score; b0 = m0.score < kInfF ? m0.bkp : 0u;
+            if (valid1) { v1 = m1.score; b1 = m1.score < kInfF ? m1.bkp : 0u; } else dead = m1.score;
+          }
+          tie[k][0] &= ~slow_mask; tie[k][1] &= ~slow_mask;
+        }
+        v0 = in ? v0 : kInfF;
+        sc[k][0] = v0; bk[k][0] = b0;
+        if (NP >= 2) { sc[k][NP >= 2 ? 1 : 0] = v1; bk[k][NP >= 2 ? 1 : 0] = b1; }
+        double w_end = kInfF;  // the word's last position
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+          my_best = dmin(my_best, sc[k][p]);
+          if (PLAIN ? p == L - 1 : (uint32_t)p + 1u == n) w_end = sc[k][p];
+        }
+        my_best = dmin(my_best, dead);
+        my_we = dmin(my_we, w_end);
+        if (in) we_cur[word[k]] = w_end;  // unpruned; next frame's replay applies this frame's limit
+      };
+#pragma unroll
+      for (int k = 0; k < NW; k++) {
+        if (kind[k] == kGPlain) neg_word(std::true_type{}, std::integral_constant<int, L>{}, k);
+        else if (kind[k] == kGSingle) neg_word(std::false_type{}, std::integral_constant<int, 1>{}, k);
+        else if (GEN && k == 0 && kind[k] == kGGeneral) neg_word(std::false_type{}, std::integral_constant<int, NPA>{}, k);
+      }
+    } else {
 #pragma unroll
     for (int k = 0; k < NW; k++) {
       if (kind[k] == kGPlain) {
@@ -276,6 +448,7 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
         }
       }
     }
+    }
 
     // ---- B: block minima through LDS ds_min_f64 cells, fed by one lane per row of 16 ---------------------------------------
     my_best = row_min_dpp(my_best);
@@ -293,6 +466,7 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
     const double best = c_best[r], we = c_we[r];
     const double limit = best + thr;
     const bool we_alive = !(we > limit) && we != kInfF;
+    if constexpr (NEG) limit_prev = limit;
     {
       uint64_t tie_any = 0;
 #pragma unroll
@@ -397,7 +571,9 @@ __global__ __launch_bounds__(1024) void decode_words_kernel(DecodeArgs a) {
   }
 }
 
-static size_t words_smem(uint32_t ld) { return kWordsCellBytes + 2 * (((size_t)ld * 8 + 16 + 1023u) & ~(size_t)1023u); }
+static size_t words_smem(uint32_t ld, uint32_t n_words = 0, bool neg = false) {
+  return kWordsCellBytes + 2 * (((size_t)ld * 8 + 16 + 1023u) & ~(size_t)1023u) + (neg ? 2 * (((size_t)n_words * 8 + 1023u) & ~(size_t)1023u) : 0);
+}
 static constexpr size_t kLdsPerWorkgroup = 160 * 1024;
 
 bool decode_words_applies(const DecodeArgs& a) { return a.words.info != nullptr && words_smem(a.ld) <= kLdsPerWorkgroup; }
@@ -408,20 +584,25 @@ hipError_t launch_decode_words(const DecodeArgs& a, hipStream_t stream) {
   if (!decode_words_applies(a)) return hipErrorInvalidValue;
   const uint32_t nw = a.words.nw, nt = a.words.nt;
   if (nw < 1 || nw > 3 || nt == 0 || nt > 1024 || nt % 64) return hipErrorInvalidValue;
-  const size_t smem = words_smem(a.ld);
+  // the model's emission costs can be negative: the variant that replays the reference's early-out (NEG), where its word-end
+  // arrays fit the LDS beside the two score rows; else the fast variant, which flags what it cannot do for the replay kernel
+  const bool neg = a.exact_negative && words_smem(a.ld, a.net.n_words, true) <= kLdsPerWorkgroup;
+  const size_t smem = words_smem(a.ld, a.net.n_words, neg);
   auto go = [&](auto kernel) {
     hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kernel, dim3(a.n_utts), dim3(nt), smem, stream, a);
     return hipGetLastError();
   };
-#define SR_WORDS_G(Lv, Gv) do { if (nw == 1) return go(decode_words_kernel<1, Lv, Gv>); if (nw == 2) return go(decode_words_kernel<2, Lv, Gv>); return go(decode_words_kernel<3, Lv, Gv>); } while (0)
+#define SR_WORDS_N(Lv, Gv, Nv, Tv) do { if (nw == 1) return go(decode_words_kernel<1, Lv, Gv, Nv, Tv>); if (nw == 2) return go(decode_words_kernel<2, Lv, Gv, Nv, Tv>); return go(decode_words_kernel<3, Lv, Gv, Nv, Tv>); } while (0)
+#define SR_WORDS_G(Lv, Gv) do { if (neg && nt <= 512) SR_WORDS_N(Lv, Gv, true, 512); if (neg) SR_WORDS_N(Lv, Gv, true, 1024); SR_WORDS_N(Lv, Gv, false, 1024); } while (0)
 #define SR_WORDS(Lv) do { if (a.words.has_general) SR_WORDS_G(Lv, true); SR_WORDS_G(Lv, false); } while (0)
   if (a.words.plain_len == 2) SR_WORDS(2);
   if (a.words.plain_len == 4) SR_WORDS(4);
   SR_WORDS(3);
 #undef SR_WORDS
 #undef SR_WORDS_G
+#undef SR_WORDS_N
 }
 
 }  // namespace srgpu

@@ -200,6 +200,62 @@ def test_negative_emission_costs_take_the_sequential_path(tmp_path, oracle_lib):
         o.close()
 
 
+@pytest.mark.parametrize("seed,W,spw,reps,M,D,var_scale,beam,wp,ragged", [
+    (321, 30, 3, 1, 2, 39, 0.004, 150.0, 2.0, False),    # the set-up of the test above on three-position words: the word-per-lane kernel
+    (322, 30, 3, 1, 2, 39, 0.004, 40.0, 0.0, False),
+    (323, 200, 2, 1, 3, 4, 0.05, 1e9, 10.0, False),      # low dimension, no pruning: every word end alive, many negative entry costs
+    (324, 120, 4, 1, 2, 6, 0.05, 60.0, 5.0, False),      # four-position words
+    (325, 64, 1, 2, 2, 4, 0.05, 1e9, 3.0, False),        # one state twice: position 1 is the word end, loop-free
+    (326, 90, 0, 0, 3, 5, 0.05, 200.0, 10.0, True),      # ragged short lexicon: silence anywhere, one-position words, words that begin in silence
+    (327, 150, 0, 0, 2, 4, 0.03, 1e9, 0.0, True),
+    (328, 1400, 3, 1, 1, 4, 0.05, 80.0, 10.0, False),    # three words per lane
+    (329, 2900, 3, 1, 1, 4, 0.05, 30.0, 10.0, False),    # more than 8192 positions: the word-per-lane kernel of a "big" lexicon
+])
+def test_negative_emission_costs_on_short_word_lexica(tmp_path, oracle_lib, seed, W, spw, reps, M, D, var_scale, beam, wp, ragged):
+    """Round 5: models whose emission costs can be negative are searched by the word-per-lane kernel's NEG variant (viterbi_words.hip),
+    which replays the reference's pre-AM early-out (Recognizer.cpp:143,173) frame by frame -- the boundary loop only for the words
+    whose entry costs are negative -- instead of handing the whole utterance to the general kernel.  Words and the traceback arrays
+    must be the oracle's, bit for bit."""
+    rng = np.random.default_rng(seed)
+    lex = synth.make_ragged_lexicon(W, rng, short=True) if ragged else synth.make_lexicon(W, spw, reps)
+    spec = synth.make_mixset(lex.n_states, M, D, seed=seed, var_floor=0.05)
+    synth.scale_variances(spec, var_scale)
+    mp = str(tmp_path / "negw.mix")
+    synth.write_mixset(mp, spec)
+    speech = [w for w in range(lex.n_words) if w != lex.silence_idx]
+    n_utts = 4 if W >= 1000 else 8
+    utts = []
+    for i in range(n_utts):
+        x = synth.sample_utterance(spec, lex, rng.choice(speech, size=3), seed=seed * 10 + i, frames_per_state=(1, 3), noise=0.9)[:60]
+        if i % 3 == 2:  # frames near NO mean in between: every cost large and positive for a while
+            x[len(x) // 2: len(x) // 2 + 4] += 3.0
+        utts.append(x.astype(np.float32))
+    off = np.concatenate([[0], np.cumsum([len(x) for x in utts])]).astype(np.uint64)
+    feats = np.concatenate(utts)
+    word_off, automaton, sil_state = lex.flatten()
+    o = oracle_lib.Oracle(mp, D, lex, am_threshold=beam, word_penalty=wp)
+    sm = o.score_matrix(feats)
+    assert (sm < 0).mean() > 1e-4, "the case has no negative emission costs"
+    with capi.Model.from_mixset(mp, D) as m:
+        lexh = m.lexicon(word_off, automaton, lex.silence_idx, (3.0, 0.0, 30.0), sil_state)
+        corpus = m.upload(feats, off)
+        words, woff, (tbs, tbw, tbb) = corpus.recognize(lexh, beam, wp, capi.GMM_EXACT, traceback=True)
+        for u in range(len(utts)):
+            w, (os_, ow, ob) = o.decode(utts[u], traceback=True)
+            assert np.array_equal(w, words[int(woff[u]):int(woff[u + 1])]), (u, w, words[int(woff[u]):int(woff[u + 1])])
+            b = int(off[u]) + u
+            assert np.array_equal(tbs[b:b + len(os_)].view(np.uint64), os_.view(np.uint64)), u
+            assert np.array_equal(tbw[b:b + len(ow)], ow) and np.array_equal(tbb[b:b + len(ob)], ob), u
+        if max(np.diff(word_off.astype(np.int64))) <= 4 and lex.n_states * 8 <= 60000:
+            # the slot-per-lane kernel + general replay (rounds 1-4's route) must agree
+            w_s, o_s, (s_s, tw_s, tb_s) = corpus.recognize(lexh, beam, wp, capi.GMM_EXACT, traceback=True, slot_kernel=True)
+            assert np.array_equal(w_s, words) and np.array_equal(o_s, woff) and np.array_equal(tw_s, tbw) and np.array_equal(tb_s, tbb)
+            assert np.array_equal(s_s.view(np.uint64), tbs.view(np.uint64))
+        corpus.close()
+        lexh.close()
+    o.close()
+
+
 def test_chunked_pipeline_matches_single_chunk(tmp_path, oracle_lib, monkeypatch):
     """A tiny score-workspace budget forces many chunks through the two-stream pipeline."""
     lex, spec, mp = _random_setup(tmp_path, 401, 60, 3, 1, 4, 39)

@@ -130,13 +130,13 @@ VGPR_BUDGET = {
     # 256 threads, two workgroups per CU = 2 waves per SIMD
     "gmm_prefilter16_kernel<3, 4>": 256,
     # 8 waves per workgroup, two workgroups per CU = 4 waves per SIMD
-    "decode_words_kernel<3, 3, false>": 128, "decode_words_kernel<1, 3, false>": 128, "decode_words_kernel<3, 4, true>": 128,
+    "decode_words_kernel<3, 3, false, false, 1024>": 128, "decode_words_kernel<1, 3, false, false, 1024>": 128, "decode_words_kernel<3, 4, true, false, 1024>": 128,
     # 1024 threads = 4 waves per SIMD (configs[4]'s lexicon: three-state rows 0 and 1, the four-state word in row 2)
     "bigram_kernel<3, 4, 3, 4>": 128, "bigram_kernel<3, 4, 3, 0>": 128,
 }
 NO_SCRATCH = ("gmm_refine_kernel<39, 32, 8, 1, 768>", "gmm_refine_kernel<39, 32, 8, 2, 768>", "gmm_refine_kernel<39, 8, 8, 1, 768>",
               "gmm_refine_kernel<63, 32, 4, 1, 512>", "gmm_refine_kernel<47, 32, 4, 2, 768>", "gmm_refine_kernel<9, 32, 8, 1, 768>",
-              "gmm_prefilter16_kernel<3, 4>", "gmm_prefilter16_kernel<4, 4>", "decode_words_kernel<3, 3, false>", "decode_words_kernel<1, 3, false>",
+              "gmm_prefilter16_kernel<3, 4>", "gmm_prefilter16_kernel<4, 4>", "decode_words_kernel<3, 3, false, false, 1024>", "decode_words_kernel<1, 3, false, false, 1024>",
               "bigram_kernel<3, 4, 3, 4>", "bigram_kernel<3, 4, 3, 0>")  # (round 4: the bigram search lost its last vector spills)
 
 

@@ -36,6 +36,10 @@ def run_case(case, seed0=0, ragged=False, tmp=None):
     speech = [w for w in range(lex.n_words) if w != lex.silence_idx]
     nm = rng.integers(1, Mhi + 1, size=lex.n_states)
     spec = synth.make_mixset(lex.n_states, nm, D, seed=case, var_floor=float(rng.choice([0.5, 1e-3])))
+    if rng.random() < 0.3:
+        # round 5: tight variances -> negative emission costs, where the reference's pre-AM early-out is live (Recognizer.cpp:143,173):
+        # the word-per-lane kernel's NEG variant on short-word lexica, the flag + replay route elsewhere
+        synth.scale_variances(spec, float(rng.choice([0.004, 0.05])))
     mp = os.path.join(tmp, "m.mix")
     synth.write_mixset(mp, spec)
     beam = float(rng.choice([15.0, 60.0, 200.0, 1e9]))
