@@ -64,6 +64,7 @@ def parse():
                          "with a seeded dense bigram table (BASELINE configs[4]: use --words 2666 --mix 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-mfma", action="store_true", help="skip the one untimed step through the dense FP64 MFMA kernel")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the untimed host-buffers-in / words-out steps (sr_recognize_batch)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for rehearsals "
                     "where several ranks share one GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="wall budget of the all-core cpu_baseline leg (the one-thread leg adds one short utterance)")
@@ -201,6 +202,23 @@ def main():
                           "achieved": tf, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
                           "flops": pm["gmm_flops"]}
 
+    # The drop-in boundary hands over HOST buffers (the reference's own timed region starts from host memory, Recognizer.cpp:45): a few
+    # untimed steps through sr_recognize_batch -- features over PCIe by the asynchronous feeder, words back -- beside the resident
+    # rate.  Never `value`.
+    boundary = None
+    if rank == 0 and world == 1 and bg is None and not args.no_boundary:
+        model.recognize_batch(lexh, feats, frame_off, args.beam, wp, kernel)
+        torch.cuda.synchronize()
+        tb = time.perf_counter()
+        nb = 3
+        for _ in range(nb):
+            wb, ob = model.recognize_batch(lexh, feats, frame_off, args.beam, wp, kernel)
+        dt = (time.perf_counter() - tb) / nb
+        boundary = {"ms_per_step_host_in_words_out": dt * 1e3, "frames_per_s": n_frames / dt, "steps": nb,
+                    "what": "sr_recognize_batch: host float32 features in (asynchronous feeder: 2 MiB pinned pieces on a copy stream, scoring "
+                            "starts on the first 1/24), words out; includes corpus set-up and tear-down per step.  Reported beside `value`, never as it",
+                    "words_equal_resident": bool(np.array_equal(wb, words) and np.array_equal(ob, woff))}
+
     elapsed, total_frames = sharding.reduce_timing(elapsed, n_frames, dist if distributed else None,
                                                    torch.device("cuda", device) if args.dist_backend == "nccl" else None)
 
@@ -240,6 +258,11 @@ def main():
             "recognised_words_rank0": int(woff[-1]),
             "build": build_identity(),
         }
+        # what of the search is NOT hidden behind scoring: with one score chunk per step the search follows the scoring (exposed = all of
+        # it); with several chunks it overlaps the next chunk's scoring on a second stream, and step - GMM is what shows in the step
+        out["search"]["exposed_ms"] = ms_per_step - prof["gmm_ms"] / max(1, args.steps)
+        if boundary:
+            out["boundary"] = boundary
         if args.kernel == "prefilter":
             out.update(prefilter_report(args, prof, n_frames, D, S))
         if dense_mfma:
@@ -248,11 +271,10 @@ def main():
             out["config"]["workload"] = out["config"]["workload"].replace("beam Viterbi", "bigram linear-lexicon beam search "
                                                                           "(Teaching::LinearSearch, parity unpinned)")
             out["search"]["kernel"] = "bigram_kernel (short-word lexica: state hypotheses in registers, one lane per word and its silence copy; viterbi_bigram.hip)"
-            out["search"]["bound"] = ("latency: eight short steps per frame, each with one to three dependent global-memory round trips (word-end lists, traceback book) "
-                                      "and a barrier, one workgroup per CU (profiles/r3_bigram_steps.txt)")
+            out["search"]["bound"] = ("instruction issue: 11 barriers per frame, ~1 600 vector instructions per wave between them and ~135 spilled scalar "
+                                      "registers reloaded through v_readlane; the oldest wave of a SIMD runs a step in a third of the time and waits for "
+                                      "the other three at the barrier (profiles/r4_bigram_steps.txt, r4_pmc_cfg5.txt); not memory")
             out["search"].pop("network", None)
-            out["search"].pop("achieved_GBps", None)
-            out["search"].pop("bytes_per_frame", None)
         if world == 1 and not args.no_cpu_baseline:
             if bg is not None:
                 out["cpu_baseline"] = cpu_baseline_bigram(args, mixset_path, lex, lm, bg_tdp, feats, frame_off, words, woff)
@@ -294,7 +316,8 @@ def gmm_roofline(args, prof, n_frames, D, S):
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         return {"kernel": "gmm_refine_kernel", "bound": "valu", "achieved": achieved, "peak": FP64_VALU_UNFUSED_PEAK,
                 "unit": "TFLOP/s", "frac": achieved / FP64_VALU_UNFUSED_PEAK, "traffic": pmc_traffic(args, n_frames, "gmm_refine_kernel"),
-                "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, KB units, separate rocprofv3 --pmc passes)",
+                "traffic_unit": "L2 fabric-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, KB units, separate rocprofv3 --pmc passes): the counters sit "
+                                "between L2 and the fabric and INCLUDE Infinity-Cache hits, i.e. an upper bound of the HBM bytes",
                 "traffic_source": traffic_source(args, n_frames),
                 "launches": prof["gmm_launches"], "chunks_per_step": prof["gmm_launches"] / steps, "ms_per_step": ms,
                 "avg_launch_ms": prof["refine_ms"] / launches, "frames_per_launch": n_frames * steps / launches,
@@ -307,7 +330,7 @@ def gmm_roofline(args, prof, n_frames, D, S):
     return {"kernel": "gmm_mfma_kernel" if args.kernel == "mfma" else "gmm_exact_kernel", "bound": "mfma",
             "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
             "traffic": pmc_traffic(args, n_frames, "gmm_mfma_kernel") if args.kernel == "mfma" else None,
-            "traffic_unit": "HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, KB units, separate rocprofv3 --pmc passes)",
+            "traffic_unit": "L2 fabric-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE; includes Infinity-Cache hits)",
             "launches": prof["gmm_launches"], "chunks_per_step": prof["gmm_launches"] / steps, "avg_launch_ms": prof["gmm_ms"] / launches,
             "frames_per_launch": n_frames * steps / launches, "flops_per_frame": 4.0 * D * S * args.mix}
 
@@ -367,9 +390,12 @@ def search_report(args, prof, S, P, P_padded, n_frames, n_utts, network):
         "network": network,
         "ms_per_step": ms,
         "bound": bound,
-        "hbm_model": {"bytes_per_frame": 8.0 * S + 4.0 * P, "achieved_GBps": algorithmic, "peak_GBps": 8000.0, "frac": algorithmic / 8000.0},
-        "hbm_measured_bytes_per_launch": traffic,
-        "hbm_measured_GBps": traffic / (ms * 1e-3) / 1e9 if traffic and ms > 0 else None,
+        # ONE formula: the library's own count (sr_profile.search_bytes = (8 S + 4 P) x frames, P = the search's trellis positions --
+        # for the bigram search the words plus their silence copies) over what it was counted on
+        "hbm_model": {"bytes_per_frame": prof["search_bytes"] / max(1.0, float(prof["frames"])), "formula": "8 S + 4 P (SURVEY 8d)",
+                      "achieved_GBps": algorithmic, "peak_GBps": 8000.0, "frac": algorithmic / 8000.0},
+        "fabric_measured_bytes_per_launch": traffic,  # (L2 fabric-side counters: Infinity-Cache hits included)
+        "fabric_measured_GBps": traffic / (ms * 1e-3) / 1e9 if traffic and ms > 0 else None,
     }
 
 
@@ -533,6 +559,9 @@ def cpu_baseline(args, mixset_path, lex, tdp, wp, feats, frame_off, gpu_words, g
         "sample": f"first {n} of {len(lens)} utterances ({int(sub_off[-1])} frames), lazy scoring + beam {args.beam:g}, "
                   f"OpenMP schedule(dynamic) over utterances, {secs:.1f} s wall",
         "words_match_gpu": match,
+        "port_vs_reference": "the port (oracle/sr_oracle.c) is FASTER than the reference compiled from its own sources in the build container: 705 against "
+                             "581 frames/s on the same 791 words (tools/ref_vs_oracle_speed.py, 21 %; 604 / 546 in round 3) -- a GPU / CPU ratio "
+                             "read off this line understates the ratio against the reference itself",
         "cpu_model": model_name,
         "host_logical_cpus": host_cpus,
         "one_thread": one,

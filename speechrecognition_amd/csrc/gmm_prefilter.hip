@@ -39,8 +39,8 @@
 //    = 6.75e-7); the accumulation probe runs its 128-term chain against 132 * 2^-24 on such a model's device.
 //
 // Limits of this path: max-approx only, <= 128 densities per mixture (a mixture of more than 32 spans 2 or 4
-// consecutive 32-slot pseudo-states), dim <= 62 (K = 2*dim + 3 <= 128); any other model is scored by the exact FP64
-// kernel (same bits).
+// consecutive 32-slot pseudo-states; up to 256 = 8 of them while the dimension is <= 39), dim <= 62 (K = 2*dim + 3 <= 128);
+// any other model is scored by the exact FP64 kernel (same bits).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -462,12 +462,16 @@ struct __attribute__((packed, aligned(4))) RowPiece { float v[4]; };  // 16 byte
 // dimension but 25 and 39 that re-read each feature from memory per evaluation; it is gone.
 // NT = threads per workgroup: 768 while the features fit a 168-register budget (DT <= 47: 161 registers there), 512 beyond (2 waves per
 // SIMD hide the LDS reads worse: dim 40 in the 47 instantiation took 27.6 ms at 512 threads, 21.2 at 768; profiles/r5_cliffs.txt).
-template <int DT, int NS, int SPW, int CH, int NT = kRThreads>
+// VS = 2 (round 5, mixtures of 129 .. 256 densities): a state is TWO halves of four chunks each.  The fp16 pass works on 4-panel groups and
+// takes its candidate limit within a group, so each half has a first candidate of its own: the main pass evaluates one per half and
+// stores the smaller; everything else is the four-chunk machinery (lists per panel, atomic minimum on the state's entry).
+template <int DT, int NS, int SPW, int CH, int NT = kRThreads, int VS = 1>
 __global__ __launch_bounds__(NT) void gmm_refine_kernel(GmmRefineArgs a) {
   static_assert(DT > 0 && (DT & 1), "padded dimension: odd");
   constexpr int kRThreads = NT, kRWaves = NT / 64;  // (shadow the file-scope defaults)
-  static_assert(CH == 1 || CH == 2 || CH == 4, "chunks per state");
-  static_assert(SPW % CH == 0 && (CH == 1 || SPW % 4 == 0), "a state's chunks live in one workgroup");
+  static_assert(CH == 1 || CH == 2 || CH == 4, "chunks per state (half)");
+  static_assert(VS == 1 || (VS == 2 && CH == 4), "two halves only of four-chunk states");
+  static_assert(SPW % (CH * VS) == 0 && (CH == 1 || SPW % 4 == 0), "a state's chunks live in one workgroup");
   extern __shared__ __attribute__((aligned(1024))) unsigned char panel_raw[];  // [SPW][state_bytes], 1 KB granular
   const uint32_t D = (uint32_t)DT, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -602,7 +606,7 @@ __global__ __launch_bounds__(NT) void gmm_refine_kernel(GmmRefineArgs a) {
   // kernel below: with the shift folded to a constant the compiler schedules the SAME instruction mix 1.0 ms slower on
   // configs[2] -- 16.0 against 15.0 ms, A/B on one box, gpurun_out/r4_ab_refine_cfg3.txt; profiles/r3_refine_closed.txt has
   // seen that before: "the present order is a local optimum somebody found")
-  const uint32_t chunk_shift = CH == 1 ? (a.chunks == 1 ? 0u : a.chunks == 2 ? 1u : 2u) : CH == 2 ? 1u : 2u;
+  const uint32_t chunk_shift = CH == 1 ? (a.chunks == 1 ? 0u : a.chunks == 2 ? 1u : 2u) : CH == 2 ? 1u : VS == 2 ? 3u : 2u;
 
   const uint32_t n_it = (uint32_t)((f_end - f_begin + kRThreads - 1) / kRThreads);
   for (uint32_t it = 0; it < n_it; it++) {
@@ -612,7 +616,7 @@ __global__ __launch_bounds__(NT) void gmm_refine_kernel(GmmRefineArgs a) {
     const uint32_t lf = it * 64u + (uint32_t)lane;
     load_x(f);
     // main pass: the first candidate of every state -- one evaluation per state in every lane, no divergence
-    constexpr int RS = SPW / CH;  // whole states of this workgroup
+    constexpr int RS = SPW / (CH * VS);  // whole states of this workgroup
     double res[RS];
     if constexpr (CH == 1) {
 #pragma unroll
@@ -698,43 +702,47 @@ __global__ __launch_bounds__(NT) void gmm_refine_kernel(GmmRefineArgs a) {
 #pragma unroll
       for (int j = 0; j < SPW; j++) mk[j] &= nd[j] >= 32 ? 0xFFFFFFFFu : ((1u << nd[j]) - 1u);  // padding slots are not densities
 #pragma unroll
-      for (int r = 0; r < RS; r++) {
+      for (int r = 0; r < RS; r++) res[r] = 1e10;  // min_score seed (Mixtures.cpp:699)
+#pragma unroll
+      for (int rv = 0; rv < RS * VS; rv++) {  // rv: a state, or one half of a state (VS = 2)
         // the chunk that holds the lane's first candidate: the first non-empty mask of the state (min_score's scan order,
         // Mixtures.cpp:700-708: densities ascending; the order does not matter for the result, see above)
-        uint32_t msel = mk[r * CH], off = 0;
+        uint32_t msel = mk[rv * CH], off = 0;
 #pragma unroll
         for (int c = 1; c < CH; c++) {
           const bool empty = msel == 0;
-          msel = empty ? mk[r * CH + c] : msel;
+          msel = empty ? mk[rv * CH + c] : msel;
           off = empty ? (uint32_t)c * state_bytes : off;
         }
-        res[r] = 1e10;  // min_score seed (Mixtures.cpp:699)
-        if (nd[r * CH]) {  // wave-uniform (a state without densities keeps the seed; chunk 0 fills first)
+        double resv = 1e10;
+        if (nd[rv * CH]) {  // wave-uniform (a state / half without densities keeps the seed; chunk 0 fills first)
           // lanes of one wave instruction now read up to CH panels, and slot d of every panel of a state shares a bank pair: 2-way
           // conflicts that cost nothing measurable (the LDS array is 41 % busy; profiles/r4_refine_chunked.txt, probe 1)
-          const double score = evaluate(panel_raw + (size_t)(r * CH) * state_bytes + off + (uint32_t)__builtin_ctz(msel | 0x80000000u) * 8u);
-          res[r] = msel != 0 ? seeded_min(score) : res[r];
+          const double score = evaluate(panel_raw + (size_t)(rv * CH) * state_bytes + off + (uint32_t)__builtin_ctz(msel | 0x80000000u) * 8u);
+          resv = msel != 0 ? seeded_min(score) : resv;
           if (counting) n_eval += (uint32_t)__builtin_popcountll(__ballot(valid));
         }
+        if constexpr (VS == 1) res[rv] = resv;
+        else res[rv / VS] = resv < res[rv / VS] ? resv : res[rv / VS];  // (equal scores have equal bits: file header)
 #pragma unroll
         for (int c = 0; c < CH; c++) {
           // what is left for the lists: the selected chunk without its first candidate; every later chunk in full (the
-          // earlier ones are empty).  The entry carries the state's best score so far; the batches lower the table entry, which
-          // the state's chunks share, with an atomic minimum where their candidate beats it.
+          // earlier ones are empty).  The entry carries the best score so far of the state (of its half); the batches lower the table
+          // entry, which the state's chunks share, with an atomic minimum where their candidate beats it.
           const bool is_sel = off == (uint32_t)c * state_bytes;
-          const uint32_t rest = is_sel ? msel & (msel - 1) : mk[r * CH + c];
-          if (nd[r * CH + c]) append(r * CH + c, valid && rest != 0, rest, res[r]);
+          const uint32_t rest = is_sel ? msel & (msel - 1) : mk[rv * CH + c];
+          if (nd[rv * CH + c]) append(rv * CH + c, valid && rest != 0, rest, resv);
         }
       }
       if (valid) {
-        double* o = a.out + f * a.ld + s0 / CH;
+        double* o = a.out + f * a.ld + s0 / (CH * VS);
         if (ns == SPW && RS >= 2) {  // ld is a multiple of 8 and s0 / CH one of RS: 16-byte aligned pairs
 #pragma unroll
           for (int r = 0; r + 1 < RS; r += 2) *reinterpret_cast<double2*>(o + r) = make_double2(res[r], res[r + 1]);
         } else {
 #pragma unroll
           for (int r = 0; r < RS; r++)
-            if ((uint32_t)(r * CH) < ns) o[r] = res[r];
+            if ((uint32_t)(r * CH * VS) < ns) o[r] = res[r];
         }
       }
     }
@@ -904,7 +912,7 @@ size_t gmm_refine_ring_words(const GmmRefineArgs& a) {
   return (size_t)g * sp * kRWaves * kRingWave;
 }
 
-template <int DT, int NS, int SPW, int CH, int NT>
+template <int DT, int NS, int SPW, int CH, int NT, int VS = 1>
 static hipError_t launch_refine_one(const GmmRefineArgs& a0, hipStream_t stream) {
   GmmRefineArgs a = a0;
   const size_t state_bytes = (size_t)(2 * DT + 2) * NS * 8;
@@ -913,7 +921,7 @@ static hipError_t launch_refine_one(const GmmRefineArgs& a0, hipStream_t stream)
   uint64_t splits;
   refine_grid(a, SPW, &n_sgroups, &splits, &a.frames_per_split);
   const dim3 grid(n_sgroups, (unsigned)splits), block(NT);
-  auto kernel = gmm_refine_kernel<DT, NS, SPW, CH, NT>;
+  auto kernel = gmm_refine_kernel<DT, NS, SPW, CH, NT, VS>;
   hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kernel, grid, block, smem, stream, a);
@@ -929,6 +937,7 @@ static hipError_t launch_refine_narrow(const GmmRefineArgs& a, hipStream_t strea
     case 32:  // (a mixture of more than 32 densities always has 32-slot panels)
       if (a.chunks == 2) return launch_refine_one<DT, 32, 8, 2, kRThreads>(a, stream);
       if (a.chunks == 4) return launch_refine_one<DT, 32, 8, 4, kRThreads>(a, stream);
+      if (a.chunks == 8) return launch_refine_one<DT, 32, 8, 4, kRThreads, 2>(a, stream);  // 129 .. 256 densities: two halves of four chunks
       return launch_refine_one<DT, 32, 8, 1, kRThreads>(a, stream);
     default: return hipErrorInvalidValue;
   }
@@ -947,7 +956,8 @@ static hipError_t launch_refine_wide(const GmmRefineArgs& a, hipStream_t stream)
 hipError_t launch_gmm_refine(const GmmRefineArgs& a, hipStream_t stream) {
   if (a.n_frames == 0) return hipSuccess;
   if (!a.ring || (uint64_t)a.dim * a.n_frames_ld * 4u >= (1ull << 32)) return hipErrorInvalidValue;  // (buffer offsets are 32 bit)
-  if (a.chunks != 1 && (a.n_slots != 32 || (a.chunks != 2 && a.chunks != 4))) return hipErrorInvalidValue;
+  if (a.chunks != 1 && (a.n_slots != 32 || (a.chunks != 2 && a.chunks != 4 && a.chunks != 8))) return hipErrorInvalidValue;
+  if (a.chunks == 8 && a.dim > 39) return hipErrorInvalidValue;  // (eight panels of one state in one workgroup's LDS: padded dimension <= 39)
   switch (a.dim) {
     case 9: return launch_refine_narrow<9>(a, stream);
     case 17: return launch_refine_narrow<17>(a, stream);

@@ -134,7 +134,8 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
   m->max_dens = std::max(1u, mx);
   m->pf_ks32 = 0;
   const uint32_t DP = gmm_refine_padded_dim(D);  // the odd dimension the refinement runs in (pairs | zeros | odd tail)
-  if (!m->max_approx || mx > 128 || 2 * D + 3 > 128 || DP == 0) return SR_OK;  // not eligible: callers get the exact kernel
+  // not eligible: callers get the exact kernel (> 128 densities per mixture need all eight panels of a state in one workgroup's LDS)
+  if (!m->max_approx || mx > 256 || (mx > 128 && DP > 39) || 2 * D + 3 > 128 || DP == 0) return SR_OK;
   const int KS = (int)((2 * D + 3 + 31) / 32);
   {
     bool preserved = false;
@@ -147,7 +148,8 @@ int pack_prefilter(sr_model* m, const uint32_t* dens_off, const double* means, c
   m->pf_dp = DP;
   // A mixture of more than 32 densities is cut into Cs = 2 or 4 chunks of 32: the kernels see S*Cs pseudo-states
   // (ps = st*Cs + chunk), the prefilter takes the minimum across a state's chunks, the refinement folds them.
-  const uint32_t Cs = mx <= 32 ? 1u : mx <= 64 ? 2u : 4u;
+  // (129 .. 256 densities: Cs = 8 = two halves of four chunks; the fp16 pass sees each half as a four-chunk state of its own)
+  const uint32_t Cs = mx <= 32 ? 1u : mx <= 64 ? 2u : mx <= 128 ? 4u : 8u;
   const uint32_t PS = S * Cs;
   m->pf_chunks = Cs;
   m->pf_pstates = PS;
@@ -422,7 +424,7 @@ int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm
     GmmPrefilterArgs pa{};
     pa.feats = d_feats; pa.n_frames = n_frames; pa.dim = m->dim;
     pa.apack = m->pf_apack.p; pa.grp_anorm = m->pf_anorm.p; pa.split_begin = m->pf_split_cur;
-    pa.mask = m->pf_mask.p; pa.nx = nx; pa.ny = m->pf_ny; pa.chunks = m->pf_chunks;
+    pa.mask = m->pf_mask.p; pa.nx = nx; pa.ny = m->pf_ny; pa.chunks = std::min(4u, m->pf_chunks);
     GmmRefineArgs ra{};
     const bool padded = m->pf_dp != m->dim;
     ra.feats = padded ? m->featsP.p : d_feats; ra.featsT = m->featsT.p; ra.n_frames = n_frames; ra.n_frames_ld = ldT; ra.dim = m->pf_dp;
@@ -443,7 +445,7 @@ int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm
     if ((rc = prof_end(m, m->s_gmm, &ep_r))) return rc;
     if ((rc = prof_end(m, m->s_gmm, &ep))) return rc;
   } else if (gmm_kernel == SR_GMM_EXACT || gmm_kernel == SR_GMM_PREFILTER) {
-    // (a model the prefilter cannot take -- sum scoring, > 128 densities per mixture, dim > 62, or a device that fails
+    // (a model the prefilter cannot take -- sum scoring, > 256 densities per mixture (> 128 beyond dim 39), dim > 62, or a device that fails
     // the fp16 probes -- is scored by the exact kernel: same bits, FP64 VALU speed)
     GmmExactArgs a{};
     a.feats = d_feats; a.n_frames = n_frames; a.dim = m->dim; a.n_states = m->n_states;
@@ -1357,7 +1359,8 @@ int sr_recognize_bigram_corpus(sr_model* m, sr_corpus* c, sr_bigram* b, const sr
     HIP_TRY(launch_bigram(ba, s_search));
     if ((rc = prof_end(m, s_search, &ep))) return rc;
     HIP_TRY(hipEventRecord(m->ev_consumed[buf], s_search));
-    if (m->profiling) m->prof.search_bytes += 8.0 * m->n_states * (double)(ch.f1 - ch.f0);
+    // SURVEY 8(d)'s decoder model, 8 S + 4 P bytes per frame, with P = the bigram search's positions (words + their silence copies)
+    if (m->profiling) m->prof.search_bytes += (8.0 * m->n_states + 4.0 * b->n_positions) * (double)(ch.f1 - ch.f0);
   }
   HIP_TRY(hipStreamSynchronize(m->s_search));
   HIP_TRY(hipStreamSynchronize(m->s_gmm));

@@ -536,7 +536,7 @@ def test_em_iteration_matches_reference_model_file(tmp_path, oracle_lib):
     (907, 16, 40, 39, 1.0, 0.5, False),     # 40 densities per mixture: two 32-slot chunks per state
     (909, 13, 64, 39, 1.0, 0.5, False),     # 64 (BASELINE configs[4] mixtures), odd state count
     (910, 11, (1, 100), 25, 1.0, 0.5, False),  # ragged up to 100 densities: four chunks, some of them empty
-    (911, 6, 130, 12, 1.0, 0.5, False),     # 130 densities: not eligible -> exact kernel, same bits
+    (911, 6, 130, 12, 1.0, 0.5, False),     # 130 densities: two halves of four chunks (round 5; the second half has 2 densities)
     (908, 16, 4, 63, 1.0, 0.5, False),      # dim 63 (K = 129): not eligible either
     (912, 9, 64, 39, 1.0, 0.5, True),       # round 4 (one evaluation per STATE): exact ties ACROSS a state's two chunks
     (913, 7, (33, 128), 39, 1.0, 0.5, True),  # three / four chunks at dim 39, ties across chunks, non-finite frames below
@@ -554,6 +554,11 @@ def test_em_iteration_matches_reference_model_file(tmp_path, oracle_lib):
     (929, 13, (1, 70), 50, 1.0, 0.5, True),  # dim 50 -> 55, up to three chunks, ties across chunks, non-finite frames
     (930, 24, 32, 62, 3.0, 0.5, False),     # dim 62 (K = 127, the limit) -> 63, features far from the means
     (931, 9, 128, 61, 1.0, 1e-3, True),     # dim 61 -> 63 (odd tail in slot 62), four full chunks, small variances
+    # round 5: 129 .. 256 densities per mixture = two halves of four chunks, each half with a candidate limit of its own
+    (932, 7, (100, 256), 39, 1.0, 0.5, True),   # ragged: states with one half and with two, ties across chunks and halves, non-finite frames
+    (933, 5, 160, 25, 1.0, 0.5, False),     # 160 everywhere (the cliff ledger's shape), dim 25
+    (934, 6, 200, 45, 1.0, 0.5, False),     # 200 densities at dim 45 (padded 47: eight panels do not fit the LDS): exact kernel
+    (935, 5, 257, 12, 1.0, 0.5, False),     # 257: beyond two halves -> exact kernel
 ])
 def test_prefilter_scores_are_bit_identical(tmp_path, oracle_lib, seed, S, M, D, scale, var_floor, dup):
     """SR_GMM_PREFILTER must return MixtureModel::score's bits: the fp16 stage may only over-select candidates."""
@@ -576,7 +581,7 @@ def test_prefilter_scores_are_bit_identical(tmp_path, oracle_lib, seed, S, M, D,
     feats[5] = 0.0
     feats[6] = 1e-20     # squares underflow in bf16/fp32
     feats[7, 0] = 250.0  # one dominant component
-    if seed in (912, 913, 929, 931):  # every density of every chunk stays a candidate: all lists, both levels, all chunks
+    if seed in (912, 913, 929, 931, 932):  # every density of every chunk stays a candidate: all lists, both levels, all chunks
         feats[9] = np.nan
         feats[10, 3] = np.inf
         feats[11, 1] = 1e30
@@ -593,7 +598,8 @@ def test_prefilter_scores_are_bit_identical(tmp_path, oracle_lib, seed, S, M, D,
     assert np.array_equal(exact.view(np.uint64), want.view(np.uint64))
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
     # which kernels produced `got`: the fp16 pass + refinement for every eligible model, the exact kernel otherwise
-    eligible = D <= 62 and int(np.max(nm)) <= 128
+    mx, padded = int(np.max(nm)), next(b for b in (9, 17, 25, 33, 39, 47, 55, 63, 999) if (D | 1) <= b)
+    eligible = D <= 62 and (mx <= 128 or (mx <= 256 and padded <= 39))
     assert (prof["prefilter_ms"] > 0 and prof["refined_densities"] >= T * S) == eligible, prof
 
 

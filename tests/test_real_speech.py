@@ -1,6 +1,7 @@
 """Real-speech parity: models trained by the REFERENCE's own Trainer on real SieTill cepstra and
 the reference's decode / alignment results for 16 test utterances (tests/golden_real/sietill_real.npz, generator
-oracle/gen_real_golden.py).  On real speech the beam prunes hard, word ends die and revive, and mixtures have
+oracle/gen_real_golden.py), and -- round 5 -- the reference's words for 64 MORE test utterances at both beams with both models
+(tests/golden_real/sietill_real_wide.npz, oracle/gen_real_golden_wide.py: raw .mm2 cepstra in, post-processed by sr::FeaturePostProcessor here).  On real speech the beam prunes hard, word ends die and revive, and mixtures have
 ragged sizes (1..8 densities) -- none of which the synthetic fixtures provide."""
 import os
 
@@ -128,3 +129,95 @@ def test_feature_post_processing_matches_reference_corpus_reader(real, tmp_path)
         got = np.fromfile(outp, dtype="<f4").reshape(-1, 25)
         want = z["feats"][off[i]:off[i + 1]]
         assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+# ---- round 5: 64 more test utterances, from the raw feature files ----------------------------------------------------------------
+WIDE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_real", "sietill_real_wide.npz")
+
+
+def _tb_digest(score, word, bkp):
+    import hashlib
+    h = hashlib.sha256()
+    h.update(np.ascontiguousarray(score, dtype="<f8").tobytes())
+    h.update(np.ascontiguousarray(word, dtype="<u2").tobytes())
+    h.update(np.ascontiguousarray(bkp, dtype="<u2").tobytes())
+    return np.frombuffer(h.digest(), dtype=np.uint8)
+
+
+@pytest.fixture(scope="module")
+def wide(real, tmp_path_factory):
+    """The 64 utterances' raw .mm2 floats through sr::read_feature_file + sr::FeaturePostProcessor (tests/cpp/host_mirror_driver.cpp):
+    must hash to what the reference's Corpus::read produced for the same files."""
+    import hashlib
+    import subprocess
+
+    from tests.test_host_mirror import DRIVER
+    from speechrecognition_amd import build
+    build.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tests", "cpp", "host_mirror_driver.cpp")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-I" + os.path.join(root, "include"), src, "-o", DRIVER,
+                           "-L" + os.path.join(root, "speechrecognition_amd"), "-lsrgpu",
+                           "-Wl,-rpath,$ORIGIN/../../speechrecognition_amd", "-Wl,-rpath,/opt/rocm/lib"])
+    z = np.load(WIDE)
+    tmp = tmp_path_factory.mktemp("wide")
+    norm = tmp / "Normalization.bin"
+    norm.write_bytes(real["normalization"].astype("<f8").tobytes())
+    ro = z["raw_off"].astype(np.int64)
+    utts = []
+    for i in range(len(ro) - 1):
+        raw, outp = tmp / f"u{i}.mm2", tmp / f"u{i}.f32"
+        raw.write_bytes(z["raw_mm2"][ro[i]:ro[i + 1]].astype("<f4").tobytes())
+        subprocess.check_output([DRIVER, "features", str(raw), str(norm), str(outp)], text=True)
+        utts.append(np.fromfile(outp, dtype="<f4").reshape(-1, int(z["dim"])))
+    got = hashlib.sha256(np.concatenate(utts).astype("<f4").tobytes()).digest()
+    assert np.array_equal(np.frombuffer(got, dtype=np.uint8), z["feats_sha256"]), "post-processed features differ from the reference's corpus reader"
+    assert np.array_equal(np.cumsum([0] + [len(u) for u in utts]), z["frame_off"].astype(np.int64))
+    return z, utts
+
+
+@pytest.mark.parametrize("pname", ["mixture", "none"])
+def test_oracle_reproduces_reference_on_64_more_utterances(real, wide, oracle_lib, tmp_path, pname):
+    z, utts = wide
+    lex = synth.sietill_lexicon()
+    mp = tmp_path / "real.mix"
+    mp.write_bytes(real[f"model_{pname}"].tobytes())
+    for tag in ("wide", "tight"):
+        key = f"{pname}_{tag}"
+        o = oracle_lib.Oracle(str(mp), int(z["dim"]), lex, tdp=tuple(z["tdp"]), am_threshold=float(z[f"{key}_beam"]),
+                              word_penalty=float(z[f"{key}_wp"]), pooling=POOL[pname])
+        for i, f in enumerate(utts):
+            w, (ts, tw, tb) = o.decode(f, traceback=True)
+            assert np.array_equal(w, z[f"{key}_words"][z[f"{key}_word_off"][i]:z[f"{key}_word_off"][i + 1]]), (key, i)
+            assert np.array_equal(_tb_digest(ts, tw, tb), z[f"{key}_tb_sha256"][i]), (key, i)
+        o.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pname", ["mixture", "none"])
+def test_gpu_matches_reference_on_64_more_utterances(real, wide, tmp_path, pname):
+    """Words = the reference's, traceback arrays = the restatement's (SHA-256 per utterance), through the default scorer and the
+    exact kernel, at both beams."""
+    from speechrecognition_amd import capi
+
+    z, utts = wide
+    lex = synth.sietill_lexicon()
+    word_off, automaton, sil = lex.flatten()
+    mp = tmp_path / "real.mix"
+    mp.write_bytes(real[f"model_{pname}"].tobytes())
+    tdp = tuple(float(x) for x in z["tdp"])
+    off = z["frame_off"].astype(np.int64)
+    with capi.Model.from_mixset(str(mp), int(z["dim"]), POOL[pname], True) as m:
+        lexh = m.lexicon(word_off, automaton, lex.silence_idx, tdp, sil)
+        corpus = m.upload(np.concatenate(utts), z["frame_off"])
+        for tag in ("wide", "tight"):
+            key = f"{pname}_{tag}"
+            for kernel in (capi.GMM_DEFAULT, capi.GMM_EXACT):
+                words, woff, (tbs, tbw, tbb) = corpus.recognize(lexh, float(z[f"{key}_beam"]), float(z[f"{key}_wp"]), kernel, traceback=True)
+                assert np.array_equal(words, z[f"{key}_words"]), (key, kernel)
+                assert np.array_equal(woff.astype(np.int64), z[f"{key}_word_off"].astype(np.int64))
+                for i in range(len(utts)):
+                    a, b = int(off[i]) + i, int(off[i + 1]) + i + 1
+                    assert np.array_equal(_tb_digest(tbs[a:b], tbw[a:b], tbb[a:b]), z[f"{key}_tb_sha256"][i]), (key, kernel, i)
+        corpus.close()
+        lexh.close()

@@ -96,7 +96,7 @@ def run_case(case, seed0=0, ragged=False, tmp=None):
             lm = (-np.log(rng.dirichlet(np.ones(nW), size=nW))).T.astype(np.float32).copy()
             tdp = np.array([[3.0, 0.0, 30.0, float(rng.choice([0.0, 5.0]))], [1.0, 0.0, 40.0, 2.0]], np.float32)
             bg_off, bg_aut = word_off, automaton
-            if rng.random() < 0.3:
+            if rng.random() < 0.3 and nW <= 400:  # (a big lexicon runs in the register layout only, which wants a one-state silence word)
                 # round 5: a silence word of two to four states with forward / skip penalties of its own -- the dense
                 # state layout, where tdp[isSilence][1..2] apply inside silence and its copies (LinearSearch.cc:296-326)
                 tdp[1] = [float(rng.choice([0.0, 1.0])), float(rng.choice([0.0, 7.0])), float(rng.choice([3.0, 40.0])), 2.0]
