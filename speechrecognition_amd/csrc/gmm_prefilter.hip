@@ -701,6 +701,37 @@ __global__ __launch_bounds__(NT) void gmm_refine_kernel(GmmRefineArgs a) {
       }
 #pragma unroll
       for (int j = 0; j < SPW; j++) mk[j] &= nd[j] >= 32 ? 0xFFFFFFFFu : ((1u << nd[j]) - 1u);  // padding slots are not densities
+      if constexpr (VS == 1) {  // (textually round 4's loop: the two-halves form below compiled 2 % slower at configs[4], profiles/r5_cliffs.txt)
+#pragma unroll
+      for (int r = 0; r < RS; r++) {
+        // the chunk that holds the lane's first candidate: the first non-empty mask of the state (min_score's scan order,
+        // Mixtures.cpp:700-708: densities ascending; the order does not matter for the result, see above)
+        uint32_t msel = mk[r * CH], off = 0;
+#pragma unroll
+        for (int c = 1; c < CH; c++) {
+          const bool empty = msel == 0;
+          msel = empty ? mk[r * CH + c] : msel;
+          off = empty ? (uint32_t)c * state_bytes : off;
+        }
+        res[r] = 1e10;  // min_score seed (Mixtures.cpp:699)
+        if (nd[r * CH]) {  // wave-uniform (a state without densities keeps the seed; chunk 0 fills first)
+          // lanes of one wave instruction now read up to CH panels, and slot d of every panel of a state shares a bank pair: 2-way
+          // conflicts that cost nothing measurable (the LDS array is 41 % busy; profiles/r4_refine_chunked.txt, probe 1)
+          const double score = evaluate(panel_raw + (size_t)(r * CH) * state_bytes + off + (uint32_t)__builtin_ctz(msel | 0x80000000u) * 8u);
+          res[r] = msel != 0 ? seeded_min(score) : res[r];
+          if (counting) n_eval += (uint32_t)__builtin_popcountll(__ballot(valid));
+        }
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+          // what is left for the lists: the selected chunk without its first candidate; every later chunk in full (the
+          // earlier ones are empty).  The entry carries the state's best score so far; the batches lower the table entry, which
+          // the state's chunks share, with an atomic minimum where their candidate beats it.
+          const bool is_sel = off == (uint32_t)c * state_bytes;
+          const uint32_t rest = is_sel ? msel & (msel - 1) : mk[r * CH + c];
+          if (nd[r * CH + c]) append(r * CH + c, valid && rest != 0, rest, res[r]);
+        }
+      }
+      } else {
 #pragma unroll
       for (int r = 0; r < RS; r++) res[r] = 1e10;  // min_score seed (Mixtures.cpp:699)
 #pragma unroll
@@ -733,6 +764,7 @@ __global__ __launch_bounds__(NT) void gmm_refine_kernel(GmmRefineArgs a) {
           const uint32_t rest = is_sel ? msel & (msel - 1) : mk[rv * CH + c];
           if (nd[rv * CH + c]) append(rv * CH + c, valid && rest != 0, rest, resv);
         }
+      }
       }
       if (valid) {
         double* o = a.out + f * a.ld + s0 / (CH * VS);
