@@ -46,6 +46,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "kernels.h"
@@ -436,6 +437,9 @@ static constexpr int kRThreads = SR_R_THREADS;   // 3 waves per SIMD; the regist
 static constexpr int kRThreadsWide = 512;        // padded dimension 55 / 63: 2 waves per SIMD, a budget of 256 registers (x in FP64: up to 126)
 static constexpr int kRWaves = kRThreads / 64;   // (the ring workspace is sized for the larger workgroup)
 static constexpr int kRBatch = SR_R_BATCH;       // dimensions per software-pipeline stage of the candidate evaluation
+#ifndef SR_DRAIN_PROBE
+#define SR_DRAIN_PROBE 0   // timing probes of gmm_drain_kernel: 1 no table atomics, 2 no feature gather (results wrong)
+#endif
 #ifndef SR_R_BATCH_WIDE
 #define SR_R_BATCH_WIDE 8
 #endif
@@ -465,9 +469,16 @@ struct __attribute__((packed, aligned(4))) RowPiece { float v[4]; };  // 16 byte
 // VS = 2 (round 5, mixtures of 129 .. 256 densities): a state is TWO halves of four chunks each.  The fp16 pass works on 4-panel groups and
 // takes its candidate limit within a group, so each half has a first candidate of its own: the main pass evaluates one per half and
 // stores the smaller; everything else is the four-chunk machinery (lists per panel, atomic minimum on the state's entry).
-template <int DT, int NS, int SPW, int CH, int NT = kRThreads, int VS = 1>
+// DEFER (round 5, mixtures of more than 32 densities): the pairs with candidates left over are not worked off in this kernel -- a batch
+// there is a cold dependent chain (list entry -> frame -> feature row -> evaluation) between main-pass iterations that have no registers
+// to prefetch with: 13 of configs[4]'s 45 ms for 0.11 evaluations per pair -- but appended to per-wave, per-panel SEGMENTS in global
+// memory (capacity a.defer_cap entries each, counts in a.defer_cnt), which gmm_drain_kernel works off afterwards with every wave on
+// batches.  A segment that is full (never at the capacity the launcher sizes: a quarter of the wave's pairs) makes the lane evaluate its
+// leftovers on the spot, from the features it still holds, into the score it is about to store.
+template <int DT, int NS, int SPW, int CH, int NT = kRThreads, int VS = 1, bool DEFER = false>
 __global__ __launch_bounds__(NT) void gmm_refine_kernel(GmmRefineArgs a) {
   static_assert(DT > 0 && (DT & 1), "padded dimension: odd");
+  static_assert(!DEFER || CH > 1, "deferred lists: states of several chunks");
   constexpr int kRThreads = NT, kRWaves = NT / 64;  // (shadow the file-scope defaults)
   static_assert(CH == 1 || CH == 2 || CH == 4, "chunks per state (half)");
   static_assert(VS == 1 || (VS == 2 && CH == 4), "two halves only of four-chunk states");
@@ -600,6 +611,14 @@ __global__ __launch_bounds__(NT) void gmm_refine_kernel(GmmRefineArgs a) {
   RingEntry* ring = reinterpret_cast<RingEntry*>(a.ring + ((uint64_t)(blockIdx.y * gridDim.x + blockIdx.x) * kRWaves + wave) * kRingWave);
   const bool counting = a.n_refined != nullptr;  // (kernel argument: a scalar branch around the bookkeeping)
   uint64_t cnt1 = 0, cnt2 = 0;  // eight 8-bit counters each (wave-uniform): frames pending per state, level 1 / level 2
+  // DEFER: this wave's segments [SPW][defer_cap] and how many entries each holds (wave-uniform)
+  const uint64_t wave_global = (uint64_t)(blockIdx.y * gridDim.x + blockIdx.x) * kRWaves + wave;
+  RingEntry* seg = DEFER ? reinterpret_cast<RingEntry*>(a.defer) + wave_global * SPW * (uint64_t)a.defer_cap : nullptr;
+  uint32_t dcnt[DEFER ? SPW : 1];
+  if constexpr (DEFER) {
+#pragma unroll
+    for (int j = 0; j < SPW; j++) dcnt[j] = 0;
+  }
   const uint64_t f_wave = f_begin + (uint64_t)wave * 64;
   auto frame_of = [&](uint32_t lf) -> uint64_t { return f_wave + (uint64_t)(lf >> 6) * kRThreads + (lf & 63u); };
   // (CH == 1 reads the shift from the kernel argument although it is 0 there, and keeps the run-time branches of the round-3
@@ -682,15 +701,33 @@ __global__ __launch_bounds__(NT) void gmm_refine_kernel(GmmRefineArgs a) {
       }
     } else {
       // appends the pairs of pseudo-state j whose lanes still hold candidates (`rest`) to j's level-1 list
-      auto append = [&](int j, bool more, uint32_t rest, double best) __attribute__((always_inline)) {
+      auto append = [&](int j, bool more, uint32_t rest, double& best) __attribute__((always_inline)) {
         const uint64_t b = __ballot(more);
         if (b) {  // wave-uniform
+          if constexpr (DEFER) {
+            const uint32_t nb = (uint32_t)__builtin_popcountll(b);
+            if (dcnt[DEFER ? j : 0] + nb <= a.defer_cap) {  // wave-uniform
+              const uint32_t pos = dcnt[DEFER ? j : 0] + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+              if (more) seg[(uint64_t)j * a.defer_cap + pos] = RingEntry{(uint32_t)f, rest, best};  // (the frame itself: n_frames < 2^30)
+              dcnt[DEFER ? j : 0] += nb;
+            } else {  // segment full: here and now, into the score the lane is about to store (the state's minimum so far)
+              uint32_t mm = more ? rest : 0u;
+              const unsigned char* panel = panel_raw + (size_t)j * state_bytes;
+              do {
+                const double score = evaluate(panel + (uint32_t)__builtin_ctz(mm | 0x80000000u) * 8u);
+                if (counting) n_eval += (uint32_t)__builtin_popcountll(__ballot(mm != 0));
+                if (mm != 0 && score < best) best = score;
+                mm &= mm - 1;
+              } while (__any(mm != 0));
+            }
+          } else {
           const uint32_t c1 = (uint32_t)(cnt1 >> (8 * j)) & 0xFFu;
           const uint32_t pos = c1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
           if (more) {
             ring[(uint32_t)j * kRingEntries + pos] = RingEntry{lf, rest, best};
           }
           cnt1 += (uint64_t)__builtin_popcountll(b) << (8 * j);
+          }
         }
       };
       uint32_t mk[SPW];
@@ -764,6 +801,7 @@ __global__ __launch_bounds__(NT) void gmm_refine_kernel(GmmRefineArgs a) {
           const uint32_t rest = is_sel ? msel & (msel - 1) : mk[rv * CH + c];
           if (nd[rv * CH + c]) append(rv * CH + c, valid && rest != 0, rest, resv);
         }
+        if constexpr (DEFER && VS == 2) res[rv / VS] = resv < res[rv / VS] ? resv : res[rv / VS];  // (a full segment lowered it in place)
       }
       }
       if (valid) {
@@ -782,6 +820,7 @@ __global__ __launch_bounds__(NT) void gmm_refine_kernel(GmmRefineArgs a) {
     // after the last iteration they are emptied.  One batch = <= 64 pairs of ONE state j (wave-uniform level, j, n):
     // level 1 evaluates each pair's second candidate, level 2 everything after the second.
     const bool last = it + 1 == n_it;
+    if constexpr (!DEFER)
     for (;;) {
       uint32_t level, j, n;
       {
@@ -864,6 +903,176 @@ __global__ __launch_bounds__(NT) void gmm_refine_kernel(GmmRefineArgs a) {
       }
     }
   }
+  if constexpr (DEFER) {
+#pragma unroll
+    for (int j = 0; j < SPW; j++)
+      if (lane == 0) a.defer_cnt[wave_global * SPW + j] = dcnt[j];
+  }
+  if (a.n_refined) {
+    if (lane == 0) atomicAdd(a.n_refined, (unsigned long long)n_eval);
+  }
+}
+
+// ---- the deferred leftovers (DEFER above): every wave on batches -----------------------------------------------------------------------
+// Same grid, same panels in LDS, same wave numbering as the gmm_refine_kernel<.., DEFER> launch before it: wave w of workgroup g works
+// off the segments that wave wrote.  A batch = 64 entries of ONE panel: the lanes fetch their entries' feature rows (the next batch's
+// entries are already in flight), evaluate each pair's next candidate and lower the table entry with an atomic minimum where it beats
+// the score the pair was listed with; pairs with more candidates move on to the wave's small level-2 list of the panel (gmm_refine_kernel's
+// ring), worked off 64 at a time, lanes looping over what is left of their masks.
+template <int DT, int NS, int SPW, int CH, int NT, int VS>
+__global__ __launch_bounds__(NT) void gmm_drain_kernel(GmmRefineArgs a) {
+  constexpr int kRWaves = NT / 64;
+  constexpr int RB = kRBatch;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char panel_raw[];
+  const uint32_t tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const uint32_t s0 = blockIdx.x * SPW;
+  const uint32_t ns = (s0 + SPW <= a.n_pstates) ? SPW : a.n_pstates - s0;
+  const uint32_t state_bytes = (2u * DT + 2u) * NS * 8u;
+  {
+    const uint32_t chunks = (ns * state_bytes + 1023u) >> 10;
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(a.rows) + (uint64_t)s0 * state_bytes + lane * 16;
+    for (uint32_t ch = wave; ch < chunks; ch += kRWaves)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (uint64_t)ch * 1024u),
+                                       (__attribute__((address_space(3))) void*)(panel_raw + ch * 1024u), 16, 0, 0);
+  }
+  const uint64_t wave_global = (uint64_t)(blockIdx.y * gridDim.x + blockIdx.x) * kRWaves + wave;
+  const RingEntry* seg = reinterpret_cast<const RingEntry*>(a.defer) + wave_global * SPW * (uint64_t)a.defer_cap;
+  RingEntry* ring = reinterpret_cast<RingEntry*>(a.ring + wave_global * kRingWave) + 8u * kRingEntries;  // the level-2 lists
+  uint32_t nj[SPW];
+#pragma unroll
+  for (int j = 0; j < SPW; j++) nj[j] = (uint32_t)j < ns ? (uint32_t)__builtin_amdgcn_readfirstlane((int)a.defer_cnt[wave_global * SPW + j]) : 0u;
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  __syncthreads();
+  const bool counting = a.n_refined != nullptr;
+  uint32_t n_eval = 0;
+  constexpr uint32_t chunk_shift = CH == 2 ? 1u : VS == 2 ? 3u : 2u;
+  uint64_t cnt2 = 0;  // eight 8-bit counters: pairs pending per panel, level 2
+
+  float xf[DT];
+  auto load_row = [&](uint64_t f) __attribute__((always_inline)) {
+    const float* xr = a.feats + f * (uint64_t)DT;
+#pragma unroll
+    for (int q = 0; q < DT / 4; q++) {
+      const RowPiece t = reinterpret_cast<const RowPiece*>(xr)[q];
+#pragma unroll
+      for (int i = 0; i < 4; i++) xf[4 * q + i] = t.v[i];
+    }
+#pragma unroll
+    for (int k = DT - DT % 4; k < DT; k++) xf[k] = xr[k];
+  };
+  // density_score_sse's operation order (Mixtures.cpp:645-690), as gmm_refine_kernel's evaluate(); the features are converted where
+  // they are used (float registers: room for the next batch's entries and rows in flight)
+  auto evaluate = [&](const unsigned char* col0) __attribute__((always_inline)) -> double {
+    const volatile __attribute__((address_space(3))) double* col = (const volatile __attribute__((address_space(3))) double*)col0;
+    double l0 = 0.0, l1 = 0.0, dist, score;
+    constexpr int NB_ = (DT + 1 + RB - 1) / RB;
+    double pm[2][RB], pv[2][RB];
+#pragma unroll
+    for (int i = 0; i < RB; i++)
+      if (i <= DT) { pm[0][i] = col[(2 * i) * NS]; pv[0][i] = col[(2 * i + 1) * NS]; }
+#pragma unroll
+    for (int b = 0; b < NB_; b++) {
+      const int cur = b & 1;
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < RB; i++) {
+        const int k = (b + 1) * RB + i;
+        if (k <= DT) { pm[cur ^ 1][i] = col[(2 * k) * NS]; pv[cur ^ 1][i] = col[(2 * k + 1) * NS]; }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < RB; i++) {
+        const int k = b * RB + i;
+        if (k < DT - 1) {
+          double u = (double)xf[k < DT ? k : 0] - pm[cur][i];
+          u = u * u;
+          u = u * pv[cur][i];
+          if (k & 1) l1 = l1 + u; else l0 = l0 + u;
+        } else if (k == DT - 1) {  // the odd tail (DT is odd)
+          dist = l0 + l1;
+          const double t = (double)xf[k < DT ? k : 0] - pm[cur][i];
+          dist += t * t * pv[cur][i];
+        } else if (k == DT) {
+          score = pm[cur][i] + dist / 2;
+          score -= pv[cur][i];
+        }
+      }
+      asm volatile("" : "+v"(l0), "+v"(l1));
+    }
+    return score;
+  };
+  // one batch: the live lanes' entries `en` of panel j (wave-uniform); level 1: one candidate each, level 2: all that is left
+  auto batch = [&](const bool l1, const uint32_t j, const RingEntry en, const bool live) __attribute__((always_inline)) {
+    uint32_t m = live ? en.mask : 0u;
+    double cur = en.score;
+    const uint64_t fb = en.lf;
+#if SR_DRAIN_PROBE == 2
+    load_row((uint64_t)(lane & 3));  // probe: no gather
+#else
+    load_row(fb);
+#endif
+    double* o = a.out + fb * a.ld + ((s0 + j) >> chunk_shift);
+    const double before = cur;
+    const unsigned char* panel = panel_raw + (size_t)j * state_bytes;
+    do {
+      const double score = evaluate(panel + (uint32_t)__builtin_ctz(m | 0x80000000u) * 8u);
+      if (counting) n_eval += (uint32_t)__builtin_popcountll(__ballot(m != 0));
+      if (m != 0 && score < cur) cur = score;
+      m &= m - 1;
+    } while (!l1 && __any(m != 0));
+    if (l1) {
+      const uint64_t b = __ballot(m != 0);
+      if (b) {
+        const uint32_t c2 = (uint32_t)(cnt2 >> (8u * j)) & 0xFFu;
+        const uint32_t pos = c2 + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+        if (m != 0) ring[j * kRingEntries + pos] = RingEntry{en.lf, m, cur};
+        cnt2 += (uint64_t)__builtin_popcountll(b) << (8u * j);
+      }
+    }
+    // (the entry was stored by the launch before this one; candidates of one pair reach it through atomics only: any order)
+#if SR_DRAIN_PROBE != 1
+    if (live && cur < before) (void)__builtin_amdgcn_global_atomic_fmin_f64((__attribute__((address_space(1))) double*)o, cur);
+#else
+    asm volatile("" :: "v"(cur), "v"(o));
+#endif
+  };
+  auto level2 = [&](const bool flush) __attribute__((always_inline)) {  // full level-2 lists (at the end: every one)
+    for (;;) {
+      const uint64_t pick = (cnt2 & 0x4040404040404040ull) ? (cnt2 & 0x4040404040404040ull) : flush ? cnt2 : 0ull;
+      if (!pick) break;
+      uint32_t j = (uint32_t)__builtin_ctzll(pick) >> 3;
+      asm volatile("" : "+s"(j));
+      const uint32_t have = (uint32_t)(cnt2 >> (8u * j)) & 0xFFu, n = have < 64u ? have : 64u;
+      cnt2 -= (uint64_t)n << (8u * j);
+      const bool live = (uint32_t)lane < n;
+      // entries stored by other lanes of this wave (level-1 batches above): wavefront-scope hand-off, as in gmm_refine_kernel
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      asm volatile("" ::: "memory");
+      const RingEntry en = ring[j * kRingEntries + have - n + (live ? (uint32_t)lane : 0u)];
+      batch(false, j, en, live);
+    }
+  };
+#pragma unroll 1
+  for (uint32_t j = 0; j < ns; j++) {
+    uint32_t n_left = 0;
+#pragma unroll
+    for (int q = 0; q < SPW; q++) n_left = (uint32_t)q == j ? nj[q] : n_left;
+    const RingEntry* sj = seg + (uint64_t)j * a.defer_cap;
+    RingEntry nxt = n_left ? sj[(uint32_t)lane < n_left ? lane : 0] : RingEntry{0u, 0u, 0.0};
+#pragma unroll 1
+    for (uint32_t pos = 0; pos < n_left; pos += 64u) {
+      const RingEntry en = nxt;
+      const uint32_t n = n_left - pos < 64u ? n_left - pos : 64u;
+      const uint32_t p2 = pos + 64u;
+      if (p2 < n_left) nxt = sj[p2 + ((uint32_t)lane < n_left - p2 ? lane : 0)];  // in flight while this batch is evaluated
+      batch(true, j, en, (uint32_t)lane < n);
+      level2(false);
+    }
+  }
+  level2(true);
   if (a.n_refined) {
     if (lane == 0) atomicAdd(a.n_refined, (unsigned long long)n_eval);
   }
@@ -933,6 +1142,10 @@ static void refine_grid(const GmmRefineArgs& a, int spw, uint32_t* n_sgroups, ui
   // two rounds of workgroups over the 256 CUs at least (one workgroup per CU when it takes the whole LDS), without
   // cutting the frame range below one pass of the threads
   uint64_t sp = std::max<uint64_t>(1, (512 + *n_sgroups - 1) / *n_sgroups);
+  if (const char* e = getenv("SRGPU_REFINE_SPLIT_FRAMES")) {  // (experiments: frame ranges whose features fit the L2s)
+    const uint64_t want = strtoull(e, nullptr, 10);
+    if (want) sp = std::max<uint64_t>(sp, (a.n_frames + want - 1) / want);
+  }
   sp = std::min<uint64_t>(sp, (a.n_frames + nt - 1) / nt);
   sp = std::max<uint64_t>(sp, 1);
   *frames_per_split = (a.n_frames + sp - 1) / sp;
@@ -944,6 +1157,25 @@ size_t gmm_refine_ring_words(const GmmRefineArgs& a) {
   return (size_t)g * sp * kRWaves * kRingWave;
 }
 
+// how many entries a wave's segment of one panel holds: a quarter of the wave's (frame, panel) pairs (configs[4]: 5 % of them are listed)
+static uint32_t defer_cap_for(const GmmRefineArgs& a, int spw) {
+  uint32_t g; uint64_t sp, fps;
+  refine_grid(a, spw, &g, &sp, &fps);
+  const uint64_t per_wave = ((fps + kRThreads - 1) / kRThreads) * 64;  // frames one wave sees
+  return (uint32_t)std::min<uint64_t>(((per_wave / 4 + 63) & ~(uint64_t)63) + 64, 1u << 30);
+}
+void gmm_refine_defer_layout(const GmmRefineArgs& a, size_t budget_bytes, uint32_t* cap, size_t* n_entries, size_t* n_counts) {
+  *cap = 0; *n_entries = 0; *n_counts = 0;
+  if (a.chunks < 2 || a.dim > 39 || a.n_slots != 32 || a.n_frames == 0) return;  // (instantiated for the 768-thread, 8-panel geometry)
+  uint32_t g; uint64_t sp, fps;
+  refine_grid(a, 8, &g, &sp, &fps);
+  uint32_t c = defer_cap_for(a, 8);
+  if (const char* e = getenv("SRGPU_DEFER_CAP")) c = std::max(1u, std::min(c, (uint32_t)strtoul(e, nullptr, 10)));  // (tests: full segments)
+  const size_t segs = (size_t)g * sp * kRWaves * 8;
+  if (segs * c * 16 > budget_bytes) return;
+  *cap = c; *n_entries = segs * c; *n_counts = segs;
+}
+
 template <int DT, int NS, int SPW, int CH, int NT, int VS = 1>
 static hipError_t launch_refine_one(const GmmRefineArgs& a0, hipStream_t stream) {
   GmmRefineArgs a = a0;
@@ -953,6 +1185,20 @@ static hipError_t launch_refine_one(const GmmRefineArgs& a0, hipStream_t stream)
   uint64_t splits;
   refine_grid(a, SPW, &n_sgroups, &splits, &a.frames_per_split);
   const dim3 grid(n_sgroups, (unsigned)splits), block(NT);
+  if constexpr (CH > 1 && NT == kRThreads && SPW == 8) {
+    if (a.defer && a.defer_cnt && a.defer_cap) {  // main pass with deferred lists, then every wave on the leftovers
+      auto k1 = gmm_refine_kernel<DT, NS, SPW, CH, NT, VS, true>;
+      auto k2 = gmm_drain_kernel<DT, NS, SPW, CH, NT, VS>;
+      hipError_t e = hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(k1, grid, block, smem, stream, a);
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+      hipLaunchKernelGGL(k2, grid, block, smem, stream, a);
+      return hipGetLastError();
+    }
+  }
+  a.defer = nullptr; a.defer_cnt = nullptr; a.defer_cap = 0;
   auto kernel = gmm_refine_kernel<DT, NS, SPW, CH, NT, VS>;
   hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return e;

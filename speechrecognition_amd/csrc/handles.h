@@ -105,6 +105,8 @@ struct sr_model {
   uint32_t pf_groups = 0, pf_ny = 0, max_dens = 0, pf_slots = 0, pf_chunks = 1, pf_pstates = 0;
   DevBuf<unsigned char> pf_apack;
   DevBuf<float> pf_anorm, featsT, featsP;  // featsP: row-major features in the refinement's padded order (only when pf_dp != dim)
+  DevBuf<uint4> pf_defer;                  // deferred leftovers of the refinement (mixtures of more than 32 densities): segments ...
+  DevBuf<uint32_t> pf_defer_cnt;           // ... and their counts (gmm_refine_defer_layout)
   int neg_possible = -1;                   // can an emission cost of this model be negative?  -1: not looked at yet (srhost::may_go_negative)
   uint32_t pf_dp = 0;                      // gmm_refine_padded_dim(dim): the odd dimension the refinement planes / featsT are laid out in
   DevBuf<uint32_t> pf_mask, pf_ndens, pf_ring;

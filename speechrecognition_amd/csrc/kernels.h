@@ -81,7 +81,15 @@ struct GmmRefineArgs {
   uint64_t frames_per_split;    // set by the launcher
   unsigned long long* n_refined;  // optional: += densities evaluated (profiling)
   uint32_t* ring;               // workspace, gmm_refine_ring_words() u32: wave-private lists of pairs with further candidates
+  // deferred leftovers (mixtures of more than 32 densities, gmm_refine_defer_layout): per wave and panel a segment of defer_cap 16-byte
+  // entries + its count; null: the lists are worked off inside the refinement kernel (rounds 2-4)
+  void* defer;
+  uint32_t* defer_cnt;
+  uint32_t defer_cap;
 };
+// workspace of the deferred-leftover route for this launch: entries per segment (0: the route does not apply -- one chunk per state, a
+// padded dimension beyond 39, or more than `budget_bytes`), total 16-byte entries, total counters
+void gmm_refine_defer_layout(const GmmRefineArgs& a, size_t budget_bytes, uint32_t* cap, size_t* n_entries, size_t* n_counts);
 size_t gmm_refine_ring_words(const GmmRefineArgs& a);  // needs n_frames, n_pstates, dim, n_slots
 hipError_t launch_gmm_prefilter(const GmmPrefilterArgs& a, int ks32, hipStream_t stream);
 int gmm_prefilter_frames_per_tile();

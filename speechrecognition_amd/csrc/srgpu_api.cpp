@@ -362,6 +362,11 @@ int resolve_dense_kernel(const sr_model* m, int gmm_kernel) {
   return gmm_kernel != SR_GMM_DEFAULT ? gmm_kernel : m->max_approx ? SR_GMM_PREFILTER : SR_GMM_MFMA;
 }
 
+static size_t defer_budget_bytes() {
+  const char* e = getenv("SRGPU_DEFER_MB");
+  return e ? (size_t)strtoull(e, nullptr, 10) << 20 : (size_t)32 << 30;
+}
+
 int reserve_scoring(sr_model* m, int gmm_kernel, uint64_t n_max) {
   gmm_kernel = resolve_dense_kernel(m, gmm_kernel);
   if ((gmm_kernel == SR_GMM_MFMA && !m->mfma_packed) || (gmm_kernel == SR_GMM_PREFILTER && !m->pf_packed)) {
@@ -388,6 +393,13 @@ int reserve_scoring(sr_model* m, int gmm_kernel, uint64_t n_max) {
     if (want_T > m->featsT.n || want_P > m->featsP.n || want_mask > m->pf_mask.n || want_ring > m->pf_ring.n) HIP_TRY(hipStreamSynchronize(m->s_gmm));
     HIP_TRY(m->featsT.ensure(want_T));
     if (want_P) HIP_TRY(m->featsP.ensure(want_P));
+    {  // deferred leftovers: within SRGPU_DEFER_MB (default 32 GiB; 0 switches the route off)
+      ra.chunks = m->pf_chunks;
+      uint32_t cap; size_t n_e, n_c;
+      gmm_refine_defer_layout(ra, defer_budget_bytes(), &cap, &n_e, &n_c);
+      if (n_e > m->pf_defer.n || n_c > m->pf_defer_cnt.n) HIP_TRY(hipStreamSynchronize(m->s_gmm));
+      if (n_e) { HIP_TRY(m->pf_defer.ensure(n_e)); HIP_TRY(m->pf_defer_cnt.ensure(n_c)); }
+    }
     HIP_TRY(m->pf_mask.ensure(want_mask));  // the refinement reads group pairs
     HIP_TRY(m->pf_ring.ensure(want_ring));
   }
@@ -433,6 +445,11 @@ int launch_scoring(sr_model* m, const float* d_feats, uint64_t n_frames, int gmm
     ra.mask = m->pf_mask.p; ra.out = d_out; ra.ld = m->ld;
     ra.n_refined = m->profiling ? m->pf_counter.p : nullptr;
     ra.ring = m->pf_ring.p;
+    {
+      uint32_t cap; size_t n_e, n_c;
+      gmm_refine_defer_layout(ra, defer_budget_bytes(), &cap, &n_e, &n_c);
+      if (cap && n_e <= m->pf_defer.n && n_c <= m->pf_defer_cnt.n) { ra.defer = m->pf_defer.p; ra.defer_cnt = m->pf_defer_cnt.p; ra.defer_cap = cap; }
+    }
     if (m->profiling) m->prof.refined_pairs += n_frames * (uint64_t)m->n_states;
     EventPair ep_p{}, ep_r{};
     if ((rc = prof_begin(m, m->s_gmm, 0, &ep))) return rc;

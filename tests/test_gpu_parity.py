@@ -773,3 +773,40 @@ def test_wave_handoff_stress():
     assert os.path.exists(exe), "tools/wave_handoff_stress is built by __graft_entry__.build()"
     r = subprocess.run([exe, "2000"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "0 stale entries, 0 wrong minima" in r.stdout, (r.stdout, r.stderr)
+
+
+@pytest.mark.parametrize("route", ["deferred", "full segments", "in-kernel lists"])
+@pytest.mark.parametrize("S,M,D", [(13, 64, 39), (7, (33, 128), 39), (5, 160, 25), (9, (40, 64), 12)])
+def test_deferred_leftovers_route_matches_the_in_kernel_lists(tmp_path, oracle_lib, monkeypatch, route, S, M, D):
+    """Round 5: for mixtures of more than 32 densities the refinement's main pass appends the pairs with candidates left over to per-wave
+    segments and gmm_drain_kernel works them off (default); a segment that is full makes the lane evaluate on the spot (forced here with
+    a capacity of 3 entries); SRGPU_DEFER_MB=0 keeps rounds 2-4's in-kernel lists.  All three: MixtureModel::score's bits."""
+    if route == "full segments":
+        monkeypatch.setenv("SRGPU_DEFER_CAP", "3")
+    elif route == "in-kernel lists":
+        monkeypatch.setenv("SRGPU_DEFER_MB", "0")
+    rng = np.random.default_rng(S * 7 + D)
+    nm = M if np.isscalar(M) else rng.integers(M[0], M[1] + 1, size=S)
+    spec = synth.make_mixset(S, nm, D, seed=S + D)
+    for dl in spec.mixtures:  # exact ties across chunks: a copy of the first density in every further chunk
+        for k in range(32, len(dl), 32):
+            src, dst = dl[0], dl[min(k + 5, len(dl) - 1)]
+            spec.mean_acc[dst] = spec.mean_acc[src]; spec.var_acc[dst] = spec.var_acc[src]
+            spec.mean_w[dst] = spec.mean_w[src]; spec.var_w[dst] = spec.var_w[src]
+    mp = str(tmp_path / "df.mix")
+    synth.write_mixset(mp, spec)
+    T = 3000
+    feats = rng.standard_normal((T, D)).astype(np.float32)
+    feats[9] = np.nan          # every density of every chunk a candidate
+    feats[10, 3] = np.inf
+    feats[100:164] *= 40.0     # a run of frames whose fp16 bound is loose: many candidates per pair, lists fill at once
+    lex = synth.make_lexicon(max(1, (S - 1) // 3), 3, 1, extra_states_last=(S - 1) % 3)
+    o = oracle_lib.Oracle(mp, D, lex)
+    want = o.score_matrix(feats)
+    o.close()
+    with capi.Model.from_mixset(mp, D) as m:
+        m.profile(True)
+        got = m.score_frames(feats, capi.GMM_PREFILTER)
+        prof = m.profile_read()
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    assert prof["refined_densities"] >= T * S

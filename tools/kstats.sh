@@ -6,7 +6,7 @@ tag=$1; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/kstats_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out -o s --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-dense-mfma --steps 5 --warmup 2 $* > $out/log.txt 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out -o s --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-dense-mfma --no-boundary --steps 5 --warmup 2 $* > $out/log.txt 2>&1
 cd $GRAFT_REPO_ROOT
 python3 - $out/s_kernel_stats.csv <<'PY'
 import csv, sys
