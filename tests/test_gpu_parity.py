@@ -810,3 +810,28 @@ def test_deferred_leftovers_route_matches_the_in_kernel_lists(tmp_path, oracle_l
         prof = m.profile_read()
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
     assert prof["refined_densities"] >= T * S
+
+
+@pytest.mark.parametrize("S,M,D", [(40, 32, 39), (24, (1, 32), 25), (21, 8, 12), (16, 16, 38), (9, 5, 1)])
+def test_shared_variances_score_bit_identically(tmp_path, oracle_lib, S, M, D):
+    """A model whose states each share ONE variance vector among their densities (mixture / global pooling, tied variances: var_idx !=
+    mean_idx): MixtureModel::score's bits from the prefilter path and the exact kernel.  (Round 5 tried a scalar-operand refinement for
+    such models: bit-identical and 7 % slower, profiles/r5_pooled_scalar_operands_experiment.txt.)"""
+    rng = np.random.default_rng(S + D)
+    nm = M if np.isscalar(M) else rng.integers(M[0], M[1] + 1, size=S)
+    spec = synth.make_mixset(S, nm, D, seed=S * 3 + D, tie_vars=True)
+    mp = str(tmp_path / "tied.mix")
+    synth.write_mixset(mp, spec)
+    T = 1500
+    feats = rng.standard_normal((T, D)).astype(np.float32)
+    feats[7] = np.nan
+    feats[8, 0] = 300.0
+    lex = synth.make_lexicon(max(1, (S - 1) // 3), 3, 1, extra_states_last=(S - 1) % 3)
+    o = oracle_lib.Oracle(mp, D, lex)
+    want = o.score_matrix(feats)
+    o.close()
+    with capi.Model.from_mixset(mp, D) as m:
+        got = m.score_frames(feats, capi.GMM_PREFILTER)
+        exact = m.score_frames(feats, capi.GMM_EXACT)
+    assert np.array_equal(exact.view(np.uint64), want.view(np.uint64))
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))

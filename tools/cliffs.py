@@ -53,9 +53,9 @@ def main():
     print(f"# {'model':34s} {'P ms':>8s} {'R ms':>8s} {'GMM ms':>8s} {'eval/pair':>9s} {'ps per dens*dim':>16s} {'vs headline':>11s}")
     base = None
 
-    def line(tag, D, M, kernel=capi.GMM_PREFILTER, mix_seed=23):
+    def line(tag, D, M, kernel=capi.GMM_PREFILTER, mix_seed=23, tie_vars=False):
         nonlocal base
-        spec = synth.make_mixset(S, M, D, seed=mix_seed)
+        spec = synth.make_mixset(S, M, D, seed=mix_seed, tie_vars=tie_vars)
         mp = os.path.join(tmp, f"m_{D}_{M}.mix")
         synth.write_mixset(mp, spec)
         feats, off = synth.make_batch(args.utts, 200, 400, D, seed=7)
@@ -72,6 +72,11 @@ def main():
     if args.only in ("", "dims"):
         for D in [int(x) for x in args.dims.split(",") if x]:
             line(f"dim {D} x 32", D, 32)
+    if args.only in ("", "pooled"):
+        # one variance vector per state (mixture pooling / tied variances): the per-density route at the untied model's speed
+        if args.only == "pooled":
+            line("dim 39 x 32 (headline)", 39, 32)
+        line("dim 39 x 32, variances tied per state", 39, 32, tie_vars=True)
     if args.only in ("", "m160"):
         line("dim 39 x 64 (configs[4] mixtures)", 39, 64)
         line("dim 39 x 128", 39, 128)
