@@ -455,7 +455,7 @@ def kernel_sources_sha16():
     return h.hexdigest()[:16]
 
 
-PMC_SUMMARIES = {"prefilter": ("r4_prefilter_summary.json", "r3_prefilter_summary.json", "r2_prefilter_summary.json"), "mfma": ("r1_mfma_summary.json",)}
+PMC_SUMMARIES = {"prefilter": ("r5_prefilter_summary.json", "r4_prefilter_summary.json", "r3_prefilter_summary.json", "r2_prefilter_summary.json"), "mfma": ("r1_mfma_summary.json",)}
 
 
 def pmc_summary(args, n_frames):

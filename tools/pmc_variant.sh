@@ -8,7 +8,7 @@ i=0
 for pmc in "$@"; do
   i=$((i+1))
   out=$GRAFT_REPO_ROOT/gpurun_out/pmc_${v}_$i
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $pmc -d $out -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py ${PMC_BENCH_ARGS:---no-cpu-baseline --steps 1 --warmup 1} > $out.log 2>&1 || { echo "pass $i FAILED"; tail -5 $out.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $pmc -d $out -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py ${PMC_BENCH_ARGS:---no-cpu-baseline --no-boundary --steps 1 --warmup 1} > $out.log 2>&1 || { echo "pass $i FAILED"; tail -5 $out.log; exit 1; }
   python3 - $out/p_counter_collection.csv <<'PY'
 import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
