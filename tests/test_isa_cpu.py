@@ -121,12 +121,15 @@ __global__ void racy(double* out, const double* in) {
 # kernel (as tools/isa_info.py prints it) -> most VGPRs its launch geometry allows
 VGPR_BUDGET = {
     # 768 threads = 3 waves per SIMD: 512 / 3 -> 168 (allocation granule 8)
-    "gmm_refine_kernel<39, 32, 8, 1, 768>": 168, "gmm_refine_kernel<39, 32, 8, 2, 768>": 168, "gmm_refine_kernel<39, 32, 8, 4, 768>": 168,
-    "gmm_refine_kernel<39, 8, 8, 1, 768>": 168, "gmm_refine_kernel<39, 16, 8, 1, 768>": 168, "gmm_refine_kernel<33, 32, 8, 1, 768>": 168,
-    "gmm_refine_kernel<47, 32, 4, 1, 768>": 168, "gmm_refine_kernel<47, 32, 4, 2, 768>": 168, "gmm_refine_kernel<47, 32, 4, 4, 768>": 168,
+    "gmm_refine_kernel<39, 32, 8, 1, 768, 1, false>": 168, "gmm_refine_kernel<39, 32, 8, 2, 768, 1, false>": 168, "gmm_refine_kernel<39, 32, 8, 4, 768, 1, false>": 168,
+    "gmm_refine_kernel<39, 8, 8, 1, 768, 1, false>": 168, "gmm_refine_kernel<39, 16, 8, 1, 768, 1, false>": 168, "gmm_refine_kernel<33, 32, 8, 1, 768, 1, false>": 168,
+    "gmm_refine_kernel<47, 32, 4, 1, 768, 1, false>": 168, "gmm_refine_kernel<47, 32, 4, 2, 768, 1, false>": 168, "gmm_refine_kernel<47, 32, 4, 4, 768, 1, false>": 168,
     # padded dimension 55 / 63: 512 threads = 2 waves per SIMD
-    "gmm_refine_kernel<55, 32, 4, 2, 512>": 256, "gmm_refine_kernel<63, 32, 4, 1, 512>": 256,
-    "gmm_refine_kernel<63, 32, 4, 4, 512>": 256, "gmm_prefilter16_kernel<4, 4>": 256,
+    "gmm_refine_kernel<55, 32, 4, 2, 512, 1, false>": 256, "gmm_refine_kernel<63, 32, 4, 1, 512, 1, false>": 256,
+    "gmm_refine_kernel<63, 32, 4, 4, 512, 1, false>": 256, "gmm_prefilter16_kernel<4, 4>": 256,
+    # mixtures of more than 32 densities: the main pass with deferred leftovers and the kernel that works them off (768 threads each)
+    "gmm_refine_kernel<39, 32, 8, 2, 768, 1, true>": 168, "gmm_refine_kernel<39, 32, 8, 4, 768, 1, true>": 168, "gmm_refine_kernel<39, 32, 8, 4, 768, 2, true>": 168,
+    "gmm_drain_kernel<39, 32, 8, 2, 768, 1>": 168, "gmm_drain_kernel<39, 32, 8, 4, 768, 2>": 168,
     # 256 threads, two workgroups per CU = 2 waves per SIMD
     "gmm_prefilter16_kernel<3, 4>": 256,
     # 8 waves per workgroup, two workgroups per CU = 4 waves per SIMD
@@ -134,8 +137,8 @@ VGPR_BUDGET = {
     # 1024 threads = 4 waves per SIMD (configs[4]'s lexicon: three-state rows 0 and 1, the four-state word in row 2)
     "bigram_kernel<3, 4, 3, 4>": 128, "bigram_kernel<3, 4, 3, 0>": 128,
 }
-NO_SCRATCH = ("gmm_refine_kernel<39, 32, 8, 1, 768>", "gmm_refine_kernel<39, 32, 8, 2, 768>", "gmm_refine_kernel<39, 8, 8, 1, 768>",
-              "gmm_refine_kernel<63, 32, 4, 1, 512>", "gmm_refine_kernel<47, 32, 4, 2, 768>", "gmm_refine_kernel<9, 32, 8, 1, 768>",
+NO_SCRATCH = ("gmm_refine_kernel<39, 32, 8, 1, 768, 1, false>", "gmm_refine_kernel<39, 32, 8, 2, 768, 1, false>", "gmm_refine_kernel<39, 8, 8, 1, 768, 1, false>",
+              "gmm_refine_kernel<63, 32, 4, 1, 512, 1, false>", "gmm_refine_kernel<47, 32, 4, 2, 768, 1, false>", "gmm_refine_kernel<9, 32, 8, 1, 768, 1, false>", "gmm_refine_kernel<39, 32, 8, 2, 768, 1, true>", "gmm_drain_kernel<39, 32, 8, 2, 768, 1>",
               "gmm_prefilter16_kernel<3, 4>", "gmm_prefilter16_kernel<4, 4>", "decode_words_kernel<3, 3, false, false, 1024>", "decode_words_kernel<1, 3, false, false, 1024>",
               "bigram_kernel<3, 4, 3, 4>", "bigram_kernel<3, 4, 3, 0>")  # (round 4: the bigram search lost its last vector spills)
 
@@ -208,17 +211,18 @@ def test_wavefront_scope_handoff_needs_no_wait_on_gfx950(tmp_path):
 
 
 def test_refinement_source_orders_its_lists_by_fences_not_by_counted_waits():
-    """gmm_refine_kernel: ONE explicit wait (vmcnt(0) behind the LDS fill), the list read-back and the atomic minimum behind
-    wavefront-scope fences.  A hand-counted vmcnt(N) in the batch loop (rounds 3-4) fails here."""
+    """gmm_refine_kernel and gmm_drain_kernel: ONE explicit wait each (vmcnt(0) behind the LDS fill), every list read-back and the
+    atomic minimum behind wavefront-scope fences.  A hand-counted vmcnt(N) in a batch loop (rounds 3-4) fails here."""
     import re
     text = open(os.path.join(ROOT, "speechrecognition_amd", "csrc", "gmm_prefilter.hip")).read()
-    body = text[text.index("void gmm_refine_kernel("):text.index("__global__ void transpose_feats_kernel")]
-    code = "\n".join(line.split("//")[0] for line in body.splitlines())
-    waits = re.findall(r"__builtin_amdgcn_s_waitcnt\(([^)]*)\)", code)
-    assert waits == ["0x0F70"], waits
-    assert "s_waitcnt" not in re.sub(r"__builtin_amdgcn_s_waitcnt\(0x0F70\)", "", code), "a wait in inline asm?"
-    at = code.index("const RingEntry en = ring[at];")
-    before = code[:at]
-    assert before.rindex('__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront")') > before.rindex("RingEntry{lf,"), "read-back must sit behind the fence pair"
-    tail = code[code.index("global_atomic_fmin_f64") - 400:code.index("global_atomic_fmin_f64")]
-    assert '__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront")' in tail
+    cut = [text.index("void gmm_refine_kernel("), text.index("void gmm_drain_kernel("), text.index("__global__ void transpose_feats_kernel")]
+    for a, b, read_back in ((cut[0], cut[1], "const RingEntry en = ring[at];"), (cut[1], cut[2], "const RingEntry en = ring[j * kRingEntries")):
+        code = "\n".join(line.split("//")[0] for line in text[a:b].splitlines())
+        waits = re.findall(r"__builtin_amdgcn_s_waitcnt\(([^)]*)\)", code)
+        assert waits == ["0x0F70"], waits
+        assert "s_waitcnt" not in re.sub(r"__builtin_amdgcn_s_waitcnt\(0x0F70\)", "", code), "a wait in inline asm?"
+        before = code[:code.index(read_back)]
+        assert before.rindex('__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront")') > before.rindex("RingEntry{"), "read-back must sit behind the fence pair"
+    refine = "\n".join(line.split("//")[0] for line in text[cut[0]:cut[1]].splitlines())
+    at = refine.rindex("global_atomic_fmin_f64")
+    assert '__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront")' in refine[at - 400:at]
