@@ -430,16 +430,10 @@ int gmm_prefilter_frames_per_tile() { return kPWaves * SR_P16_NB * 16; }
 #ifndef SR_R_BATCH
 #define SR_R_BATCH 4
 #endif
-#ifndef SR_R_XCDMAP
-#define SR_R_XCDMAP 0         // 1: state groups 2k, 2k + 1 on one XCD (probe, profiles/r5_refine_order_and_xcdmap.txt)
-#endif
 static constexpr int kRThreads = SR_R_THREADS;   // 3 waves per SIMD; the register budget of 168 holds x in FP64 (78) + pipeline
 static constexpr int kRThreadsWide = 512;        // padded dimension 55 / 63: 2 waves per SIMD, a budget of 256 registers (x in FP64: up to 126)
 static constexpr int kRWaves = kRThreads / 64;   // (the ring workspace is sized for the larger workgroup)
 static constexpr int kRBatch = SR_R_BATCH;       // dimensions per software-pipeline stage of the candidate evaluation
-#ifndef SR_DRAIN_PROBE
-#define SR_DRAIN_PROBE 0   // timing probes of gmm_drain_kernel: 1 no table atomics, 2 no feature gather (results wrong)
-#endif
 #ifndef SR_R_BATCH_WIDE
 #define SR_R_BATCH_WIDE 8
 #endif
@@ -486,15 +480,7 @@ __global__ __launch_bounds__(NT) void gmm_refine_kernel(GmmRefineArgs a) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char panel_raw[];  // [SPW][state_bytes], 1 KB granular
   const uint32_t D = (uint32_t)DT, tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-#if SR_R_XCDMAP
-  // probe: the two workgroups that fill the two 64-byte halves of one 128-byte table line on ONE XCD (blocks b and
-  // b + 8 share an XCD under the dispatcher's round-robin placement: speed only).  Within every full run of 16 blocks.
-  const uint32_t bid = blockIdx.x;
-  const uint32_t sg = (bid | 15u) < gridDim.x ? ((bid & ~15u) | ((bid & 7u) << 1) | ((bid >> 3) & 1u)) : bid;
-  const uint32_t s0 = sg * SPW;
-#else
   const uint32_t s0 = blockIdx.x * SPW;
-#endif
   const uint32_t ns = (s0 + SPW <= a.n_pstates) ? SPW : a.n_pstates - s0;  // (pseudo-)states of this workgroup
   const uint32_t state_bytes = (2u * D + 2u) * NS * 8u;
   const uint64_t f_begin = (uint64_t)blockIdx.y * a.frames_per_split;
@@ -1007,11 +993,7 @@ __global__ __launch_bounds__(NT) void gmm_drain_kernel(GmmRefineArgs a) {
     uint32_t m = live ? en.mask : 0u;
     double cur = en.score;
     const uint64_t fb = en.lf;
-#if SR_DRAIN_PROBE == 2
-    load_row((uint64_t)(lane & 3));  // probe: no gather
-#else
     load_row(fb);
-#endif
     double* o = a.out + fb * a.ld + ((s0 + j) >> chunk_shift);
     const double before = cur;
     const unsigned char* panel = panel_raw + (size_t)j * state_bytes;
@@ -1031,11 +1013,7 @@ __global__ __launch_bounds__(NT) void gmm_drain_kernel(GmmRefineArgs a) {
       }
     }
     // (the entry was stored by the launch before this one; candidates of one pair reach it through atomics only: any order)
-#if SR_DRAIN_PROBE != 1
     if (live && cur < before) (void)__builtin_amdgcn_global_atomic_fmin_f64((__attribute__((address_space(1))) double*)o, cur);
-#else
-    asm volatile("" :: "v"(cur), "v"(o));
-#endif
   };
   auto level2 = [&](const bool flush) __attribute__((always_inline)) {  // full level-2 lists (at the end: every one)
     for (;;) {
@@ -1142,10 +1120,6 @@ static void refine_grid(const GmmRefineArgs& a, int spw, uint32_t* n_sgroups, ui
   // two rounds of workgroups over the 256 CUs at least (one workgroup per CU when it takes the whole LDS), without
   // cutting the frame range below one pass of the threads
   uint64_t sp = std::max<uint64_t>(1, (512 + *n_sgroups - 1) / *n_sgroups);
-  if (const char* e = getenv("SRGPU_REFINE_SPLIT_FRAMES")) {  // (experiments: frame ranges whose features fit the L2s)
-    const uint64_t want = strtoull(e, nullptr, 10);
-    if (want) sp = std::max<uint64_t>(sp, (a.n_frames + want - 1) / want);
-  }
   sp = std::min<uint64_t>(sp, (a.n_frames + nt - 1) / nt);
   sp = std::max<uint64_t>(sp, 1);
   *frames_per_split = (a.n_frames + sp - 1) / sp;

@@ -85,18 +85,19 @@ def main():
         # zerogram search with negative emission costs on the headline lexicon: variances x 0.004 as in
         # tests/test_gpu_parity.py::test_negative_emission_costs..., features drawn near the means so that costs do go negative
         D, M = 39, 32
-        for scale, tag in ((1.0, "search, costs >= 0 (headline)"), (0.004, "search, negative emission costs")):
+        for scale, tag, wl in ((1.0, "search, costs >= 0 (headline)", (1333, 3)), (0.004, "search, negative emission costs", (1333, 3)),
+                               (1.0, "search, 12-position words, >= 0", (333, 12)), (0.004, "search, 12-position words, negative", (333, 12))):
+            lex = synth.make_lexicon(wl[0], wl[1], 1, extra_states_last=S - 1 - wl[0] * wl[1])
             spec = synth.make_mixset(S, M, D, seed=23, var_floor=0.5 if scale == 1.0 else 0.002)
             if scale != 1.0:
                 synth.scale_variances(spec, scale)
             mp = os.path.join(tmp, f"neg_{scale}.mix")
             synth.write_mixset(mp, spec)
-            lex = synth.make_lexicon(1333, 3, 1)
             rng = np.random.default_rng(5)
             utts, lens = [], []
             for u in range(args.utts):
                 T = int(rng.integers(200, 401))
-                x = synth.sample_utterance(spec, lex, rng.integers(1, lex.n_words, size=12), seed=1000 + u, frames_per_state=(3, 7), noise=0.8)
+                x = synth.sample_utterance(spec, lex, rng.integers(1, lex.n_words, size=12 if wl[1] == 3 else 4), seed=1000 + u, frames_per_state=(3, 7), noise=0.8)
                 while len(x) < T:
                     x = np.concatenate([x, x])
                 x = x[:T]
