@@ -122,7 +122,9 @@ SR_API int sr_corpus_wait(sr_corpus* c);
  * call, and nine allocations per batch cost about a millisecond -- if they hold at most SRGPU_SPARE_MB MiB together (default 256;
  * 0 keeps nothing); one set is kept, until the next upload adopts it, sr_model_trim() or sr_model_destroy(). */
 SR_API int sr_corpus_destroy(sr_corpus* c);
-/* Releases what the model keeps for reuse between calls (the parked buffers above). */
+/* Releases what the model keeps for reuse between calls: the parked buffers above, and the scoring path's deferred-leftover segments
+ * (models of more than 32 densities per mixture; up to SRGPU_DEFER_MB, 23 GB at 8000 states x 64 densities / 302 685 frames) --
+ * the next scoring call allocates them again. */
 SR_API int sr_model_trim(sr_model* m);
 
 /* ---- scoring: FeatureScorer::prepare_sequence + score (FeatureScorer.hpp:14-15) -------------------

@@ -840,6 +840,8 @@ int sr_model_trim(sr_model* m) {
   HIP_TRY(hipDeviceSynchronize());
   std::unique_ptr<CorpusSpare> sp;
   { std::lock_guard<std::mutex> lk(m->spare_mu); sp = std::move(m->spare); }
+  // ... and the refinement's deferred-leftover segments (23 GB at configs[4]); the next scoring call allocates them again
+  m->pf_defer.release(); m->pf_defer_cnt.release();
   return SR_OK;  // (sp's buffers are freed here)
   });
 }
