@@ -835,3 +835,29 @@ def test_shared_variances_score_bit_identically(tmp_path, oracle_lib, S, M, D):
         exact = m.score_frames(feats, capi.GMM_EXACT)
     assert np.array_equal(exact.view(np.uint64), want.view(np.uint64))
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+def test_deferred_leftovers_across_score_chunks_and_the_feeder(tmp_path, oracle_lib, monkeypatch):
+    """Mixtures of 40 densities (two chunks per state: the deferred-leftover route) with a score-table budget that cuts the corpus into
+    many chunks -- the segments are one workspace reused launch after launch on the scoring stream while the search of the previous chunk
+    runs beside it -- and through sr_recognize_batch's asynchronous feeder (four scoring launches per chunk): words as with one chunk."""
+    lex, spec, mp = _random_setup(tmp_path, 451, 40, 3, 1, 40, 39)
+    feats, off = synth.make_batch(60, 30, 90, 39, seed=452)
+    word_off, automaton, sil_state = lex.flatten()
+    results = []
+    for mb in ("4096", "1"):
+        monkeypatch.setenv("SRGPU_SCORE_CHUNK_MB", mb)
+        with capi.Model.from_mixset(mp, 39) as m:
+            lexh = m.lexicon(word_off, automaton, lex.silence_idx, (3.0, 0.0, 30.0), sil_state)
+            corpus = m.upload(feats, off)
+            results.append((corpus.recognize(lexh, 200.0, 10.0, capi.GMM_PREFILTER), corpus.score(capi.GMM_PREFILTER),
+                            m.recognize_batch(lexh, feats, off, 200.0, 10.0, capi.GMM_PREFILTER)))
+            corpus.close()
+            lexh.close()
+    (w0, o0), s0, (b0, bo0) = results[0]
+    (w1, o1), s1, (b1, bo1) = results[1]
+    assert np.array_equal(w0, w1) and np.array_equal(o0, o1) and np.array_equal(b0, w0) and np.array_equal(b1, w0) and np.array_equal(bo1, o0)
+    assert np.array_equal(s0.view(np.uint64), s1.view(np.uint64))
+    o = oracle_lib.Oracle(mp, 39, lex)
+    assert np.array_equal(o.score_matrix(feats[:500]).view(np.uint64), s0[:500].view(np.uint64))
+    o.close()
