@@ -53,7 +53,8 @@ SR_API int sr_abi_version(void);
 
 /* GMM scoring kernels (MixtureModel::score, Mixtures.cpp:737-744) */
 #define SR_GMM_MFMA 0   /* dense FP64 MFMA contraction + fused min / -log-sum-exp epilogue (<= 1e-9 relative, ~1e-15 on
-                           well-conditioned models; what SR_GMM_DEFAULT picks for sum scoring) */
+                           well-conditioned models; what SR_GMM_DEFAULT picks for sum scoring).  Dimension <= 63; a model of
+                           dimension 64 .. 160 (the largest the library takes) is scored by SR_GMM_EXACT's kernel instead */
 #define SR_GMM_EXACT 1  /* direct form replaying density_score_sse's operation order (Mixtures.cpp:645-690): bit-exact */
 #define SR_GMM_PREFILTER 2  /* bit-exact like SR_GMM_EXACT: a 16-bit MFMA prefilter selects the densities that can be the
                                minimum, FP64 replays only those.  Max-approx models with <= 128 densities per mixture and

@@ -114,6 +114,12 @@ static hipError_t launch_d(const GmmExactArgs& a, bool sum, uint32_t n_splits, c
   const dim3 grid(L.states ? n_blocks : (unsigned)((a.n_frames + kExactThreads - 1) / kExactThreads), L.states ? 1 : n_splits),
       block(kExactThreads);
   const size_t shmem = DS ? 0 : (size_t)a.dim * kExactThreads * sizeof(float);
+  if (shmem > 160 * 1024) return hipErrorInvalidValue;  // (dim <= 160: srhost::model_shell refuses larger models)
+  if (shmem > 48 * 1024) {  // the run-time-dimension path keeps a workgroup's frames in LDS: beyond the default dynamic size from dim 48
+    hipError_t e = sum ? hipFuncSetAttribute((const void*)gmm_exact_kernel<DS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem)
+                       : hipFuncSetAttribute((const void*)gmm_exact_kernel<DS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) return e;
+  }
   if (sum)
     hipLaunchKernelGGL((gmm_exact_kernel<DS, true>), grid, block, shmem, stream, a.feats, a.n_frames, a.dim, a.n_states,
                        a.dens_off, a.means, a.inv_vars, a.norm, a.logw, a.out, a.ld, a.states_per_split, L);

@@ -359,7 +359,9 @@ int prof_end(sr_model* m, hipStream_t s, EventPair* ep) {
 // max-approx models; for sum scoring (Mixtures.cpp:719-728) the FP64-MFMA kernel with its fused -log sum exp epilogue, within
 // SR_GMM_MFMA's 1e-9 (the direct form stays 1e-12 from the reference's libm in sum mode, at 3x the time: SR_GMM_EXACT on request).
 int resolve_dense_kernel(const sr_model* m, int gmm_kernel) {
-  return gmm_kernel != SR_GMM_DEFAULT ? gmm_kernel : m->max_approx ? SR_GMM_PREFILTER : SR_GMM_MFMA;
+  if (gmm_kernel == SR_GMM_DEFAULT) gmm_kernel = m->max_approx ? SR_GMM_PREFILTER : SR_GMM_MFMA;
+  if (gmm_kernel == SR_GMM_MFMA && m->ksteps == 0) gmm_kernel = SR_GMM_EXACT;  // dimension 64 .. 160: the exact kernel (tighter, not looser)
+  return gmm_kernel;
 }
 
 static size_t defer_budget_bytes() {
@@ -624,8 +626,9 @@ int model_shell(int device, uint32_t dim, uint32_t n_states, const uint32_t* den
   *out = nullptr;
   if (!dens_off) return fail(SR_EINVAL, "null model table");
   if (dim == 0 || n_states == 0) return fail(SR_EINVAL, "dim and n_states must be positive");
+  // (0 beyond dimension 63: no dense FP64-MFMA instantiation -- SR_GMM_MFMA is then answered by the exact kernel, resolve_dense_kernel)
   const int ks = gmm_mfma_ksteps_for_dim(dim);
-  if (ks == 0) return fail(SR_ELIMIT, "dim %u unsupported (max 63)", dim);
+  if (dim > 160) return fail(SR_ELIMIT, "dim %u unsupported (max 160: the exact kernel keeps a workgroup's frames in LDS)", dim);
   if (dens_off[0] != 0) return fail(SR_EINVAL, "dens_off[0] must be 0");
   for (uint32_t s = 0; s < n_states; s++)
     if (dens_off[s + 1] < dens_off[s]) return fail(SR_EINVAL, "dens_off must be non-decreasing (state %u)", s);

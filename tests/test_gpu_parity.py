@@ -318,10 +318,10 @@ def test_error_paths():
     with pytest.raises(capi.SrError) as e:
         capi.Model.from_mixset("/nonexistent.mix", 39)
     assert e.value.code == -1 and "cannot open" in str(e.value)
-    means = np.zeros((2, 70))
+    means = np.zeros((2, 161))
     with pytest.raises(capi.SrError) as e:
         capi.Model.from_tables([0, 1, 2], means, means + 1, np.zeros(2), np.zeros(2))
-    assert e.value.code == -4  # dim > 63
+    assert e.value.code == -4  # dim > 160 (round 5: 64 .. 160 run the exact kernel, test_dimensions_beyond_the_matrix_core_kernels)
 
 
 def test_cfg2_single_long_utterance(tmp_path, oracle_lib):
@@ -860,4 +860,46 @@ def test_deferred_leftovers_across_score_chunks_and_the_feeder(tmp_path, oracle_
     assert np.array_equal(s0.view(np.uint64), s1.view(np.uint64))
     o = oracle_lib.Oracle(mp, 39, lex)
     assert np.array_equal(o.score_matrix(feats[:500]).view(np.uint64), s0[:500].view(np.uint64))
+    o.close()
+
+
+@pytest.mark.parametrize("D,max_approx", [(64, True), (100, True), (160, True), (77, False)])
+def test_dimensions_beyond_the_matrix_core_kernels(tmp_path, oracle_lib, D, max_approx):
+    """MixtureModel::density_score_sse is dimension-generic (Mixtures.cpp:645-690).  Round 5: dimensions 64 .. 160 are taken (rounds 1-4
+    refused dim > 63); every scoring selector resolves to the exact kernel there -- SR_GMM_MFMA has no instantiation, the prefilter path ends
+    at 62 -- so scores are MixtureModel::score's bits (1e-12 with sum scoring: device exp / log), words, tracebacks and alignments the oracle's."""
+    lex = synth.make_lexicon(12, 3, 1)
+    spec = synth.make_mixset(lex.n_states, 3, D, seed=600 + D)
+    mp = str(tmp_path / "wide.mix")
+    synth.write_mixset(mp, spec)
+    rng = np.random.default_rng(D)
+    utts = [synth.sample_utterance(spec, lex, rng.integers(1, lex.n_words, size=3), seed=610 + i)[:50].astype(np.float32) for i in range(3)]
+    off = np.concatenate([[0], np.cumsum([len(x) for x in utts])]).astype(np.uint64)
+    feats = np.concatenate(utts)
+    word_off, automaton, sil_state = lex.flatten()
+    o = oracle_lib.Oracle(mp, D, lex, am_threshold=120.0, max_approx=max_approx)
+    want = o.score_matrix(feats)
+    with capi.Model.from_mixset(mp, D, capi.POOL_NONE, max_approx) as m:
+        for kernel in (capi.GMM_DEFAULT, capi.GMM_MFMA, capi.GMM_PREFILTER, capi.GMM_EXACT):
+            got = m.score_frames(feats, kernel)
+            if max_approx:
+                assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), kernel
+            else:
+                _assert_scores_close(got, want, rtol=1e-12)
+        lexh = m.lexicon(word_off, automaton, lex.silence_idx, (3.0, 0.0, 30.0), sil_state)
+        corpus = m.upload(feats, off)
+        words, woff, (tbs, tbw, tbb) = corpus.recognize(lexh, 120.0, 10.0, capi.GMM_DEFAULT, traceback=True)
+        aut = np.asarray([sil_state] + list(automaton[word_off[1]:word_off[2]]) + [sil_state], np.uint16)
+        st, cost = corpus.align([aut] * 3, (3.0, 0.0, 30.0), sil_state, capi.GMM_DEFAULT)
+        for u, x in enumerate(utts):
+            w, (os_, ow, ob) = o.decode(x, traceback=True)
+            assert np.array_equal(w, words[int(woff[u]):int(woff[u + 1])])
+            b = int(off[u]) + u
+            assert np.array_equal(tbw[b:b + len(ow)], ow) and np.array_equal(tbb[b:b + len(ob)], ob)
+            if max_approx:
+                assert np.array_equal(tbs[b:b + len(os_)].view(np.uint64), os_.view(np.uint64))
+                s_, c_ = o.align_full(x, aut)
+                assert np.array_equal(st[int(off[u]):int(off[u + 1])], s_) and cost[u] == c_
+        corpus.close()
+        lexh.close()
     o.close()

@@ -28,7 +28,7 @@ def run_case(case, seed0=0, ragged=False, tmp=None):
     reps = int(rng.integers(1, 3))
     if spw * reps < 2:
         reps = 2  # (the decoder wants a word with two or more positions: sr_lexicon_create's documented limit)
-    D = int(rng.choice([1, 4, 12, 25, 26, 33, 39, 40, 46, 47, 50, 62, 63]))  # (round 5: every dimension <= 62 on the prefilter path; 63: exact kernel)
+    D = int(rng.choice([1, 4, 12, 25, 26, 33, 39, 40, 46, 47, 50, 62, 63, 64, 90]))  # (round 5: every dimension <= 62 on the prefilter path; 63 .. 160: exact kernel)
     Mhi = int(rng.choice([1, 3, 8, 33, 70, 100]))  # (33 / 70 / 100: two, three and four 32-slot chunks per state in the refinement)
     if W >= 1000:
         Mhi = min(Mhi, 3)
@@ -128,7 +128,7 @@ def run_case(case, seed0=0, ragged=False, tmp=None):
     o.close()
     # sum scoring (max-approx false, Mixtures.cpp:719-728) through SR_GMM_DEFAULT = the FP64-MFMA kernel (round 4) and through the
     # direct-form kernel: 1e-9 / 1e-12 of the oracle (device exp / log); on the small cases only (the oracle's dense sum-mode matrix)
-    if lex.n_states * int(off[-1]) <= 400000 and D <= 46:
+    if lex.n_states * int(off[-1]) <= 400000:
         o = pyoracle.Oracle(mp, D, lex, am_threshold=beam, max_approx=False)
         want_sum = o.score_matrix(feats)
         o.close()
