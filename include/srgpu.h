@@ -82,7 +82,8 @@ SR_API int sr_device_count(int* count);
  *   dens_off[n_states+1]  densities of state s are rows dens_off[s] .. dens_off[s+1]-1
  *   means, inv_vars       [C x dim] doubles (means_, vars_inv_);  norm, logw  [C] (norm_, mean_weights_log_)
  *   max_approx            1: min_score (Mixtures.cpp:696-713), 0: sum_score (:719-728)
- * Limits: dim <= 63, C < 2^31.  (The reference itself stops at 65535 densities, Mixtures.cpp:766.) */
+ * Limits: dim <= 160 (the matrix-core kernels end at 63 and 62: the exact kernel scores what lies beyond), C < 2^31.  (The reference
+ * itself stops at 65535 densities, Mixtures.cpp:766.) */
 SR_API int sr_model_create(int device, uint32_t dim, uint32_t n_states, const uint32_t* dens_off,
                     const double* means, const double* inv_vars, const double* norm, const double* logw,
                     int max_approx, sr_model** out);
